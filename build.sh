@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# Builds libjcdf_hip.so (gfx950 only) and the CPU oracle library, in-tree.
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+PKG="$ROOT/juliachem.jl_amd"
+mkdir -p "$PKG/lib" "$ROOT/oracle/_build"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread \
+    -Wall -Wno-unused-function \
+    -I"$ROOT/include" \
+    "$PKG/csrc/jcdf_api.hip" -o "$PKG/lib/libjcdf_hip.so" "$@"
+gcc -O2 -fPIC -shared -o "$ROOT/oracle/_build/libjcdf_oracle.so" "$ROOT/oracle/c/jcdf_oracle.c"
+echo "built: $PKG/lib/libjcdf_hip.so  $ROOT/oracle/_build/libjcdf_oracle.so"

@@ -1,0 +1,170 @@
+/* jcdf.h — C ABI of libjcdf_hip.so: MI355X (gfx950) density-fitted RHF Fock build.
+ *
+ * Drop-in boundary for ONE path of JuliaChem.jl: the GPU density-fitted Fock
+ * build that `df_rhf_fock_build!` dispatches to
+ *   /root/reference/src/rhf/energy/DensityFitting/DensityFitting.jl:51-52,78-90
+ *   -> df_rhf_fock_build_GPU!        (GPUDF.jl:11-304)
+ *   -> df_rhf_fock_build_dense_GPU!  (DenseGPUDF.jl:9-162)
+ * Each entry point below names the reference code it replaces.  INTEGRATION.md
+ * shows the Julia `ccall` stubs a maintainer adds (julia/JCDFHip.jl).
+ *
+ * Conventions
+ *   - plain C: pointers + int64 sizes, no C++/torch types.  Every function
+ *     returns int32 status (0 = ok, != 0 see jcdf_status); the message is read
+ *     with jcdf_last_error().  No exception crosses the boundary.
+ *   - host matrices are Julia arrays: column-major fp64, first index fastest.
+ *     Index arrays are int64 and 0-BASED on this side (the glue subtracts 1).
+ *   - the caller owns every host pointer; the library copies before returning
+ *     and never retains a host pointer (Julia GC may move/free it afterwards).
+ *   - one handle == one HIP device == one auxiliary-index shard (the reference's
+ *     "global device id", GPUDF.jl:1026-1056).  Handles are independent; the
+ *     caller sums the per-shard Fock matrices (reference: host axpy
+ *     GPUDF.jl:267-277 and MPI.Allreduce! DensityFitting.jl:68-71; here: RCCL
+ *     all-reduce on the device buffer returned by jcdf_fock_build_device).
+ *   - calls on one handle must come from one host thread at a time.
+ */
+#ifndef JCDF_H
+#define JCDF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jcdf_handle jcdf_handle;
+
+enum jcdf_status {
+    JCDF_OK = 0,
+    JCDF_ERR_INVALID = 1,     /* bad argument / call order                      */
+    JCDF_ERR_HIP = 2,         /* a HIP runtime call failed                      */
+    JCDF_ERR_NO_DEVICE = 3,   /* no usable gfx950 device (product path has NO CPU fallback) */
+    JCDF_ERR_ALLOC = 4,
+    JCDF_ERR_NOT_SPD = 5,     /* metric (P|Q) not positive definite             */
+    JCDF_ERR_INTERNAL = 6
+};
+
+/* Per-call device timings in seconds, measured with HIP events on the handle's
+ * stream.  Field names follow the reference's JCTiming keys
+ * (shared/JCTiming.jl:52-105: "GPU_-N-_W_time-", "GPU_-N-_K_time-", ...;
+ * written at GPUDF.jl:280-301 / DenseGPUDF.jl:139-160). */
+typedef struct jcdf_timings {
+    double non_zero_coeff_time; /* C_occ staging (replaces build_non_zero_coefficients_kernel, GPUDF.jl:459-480) */
+    double W_time;              /* exchange intermediate W (+ fused V)   GPUDF.jl:637-667 / DenseGPUDF.jl:107 */
+    double K_time;              /* K = W^T W                             GPUDF.jl:669-826 / DenseGPUDF.jl:111 */
+    double V_time;              /* 0: V is produced inside the W pass    GPUDF.jl:539-542 */
+    double J_time;              /* J = 2 B^T V                           GPUDF.jl:544-547 */
+    double density_time;        /* 0 unless the density is requested     GPUDF.jl:327-345 */
+    double H_add_time;          /* folded into assemble                  GPUDF.jl:221-225 */
+    double copy_J_time;         /* assemble: J scatter + symmetrise + H  GPUDF.jl:482-536 */
+    double fock_time;           /* whole device Fock build               "GPU_-N-_fock_time-" */
+    double copy_time;           /* H2D C_occ + D2H F (host entry only)   GPUDF.jl:206,267-277 */
+} jcdf_timings;
+
+/* Kernel launch records of the most recent jcdf_fock_build*: one entry per
+ * kernel launched (name, average seconds, algorithmic flops and bytes).  Used by
+ * bench.py for the roofline object. */
+typedef struct jcdf_kernel_stat {
+    char name[48];
+    double seconds;
+    double flops;      /* executed fp64 flops (incl. padding)   */
+    double alg_flops;  /* algorithmic flops (SURVEY 8d formula) */
+    double alg_bytes;  /* algorithmic HBM bytes                 */
+} jcdf_kernel_stat;
+
+/* ---- lifetime -------------------------------------------------------------- */
+/* Replaces get_default_gpu_data_cuda() (shared/GPUData_cuda.jl:40-46) + the
+ * CUDA.device!() selection (GPUDF.jl:192).  Fails with JCDF_ERR_NO_DEVICE when
+ * no HIP device exists — there is no CPU fallback. */
+int32_t jcdf_create(jcdf_handle **out, int32_t device_id);
+/* Replaces CUDA.unsafe_free!/GC of the device arrays (GPUDF.jl:1001-1006). */
+int32_t jcdf_destroy(jcdf_handle *h);
+/* Message of the last failing call on `h` (h == NULL: last jcdf_create failure). */
+const char *jcdf_last_error(const jcdf_handle *h);
+/* ABI version of this header (major*1000 + minor). */
+int32_t jcdf_abi_version(void);
+
+/* ---- setup (iteration == 1 branch, GPUDF.jl:37-165 / DenseGPUDF.jl:29-72) ---- */
+/* Problem sizes + the packed pq layout + this handle's aux shard.
+ *   N        scf_data.mu  (# AO)                    DensityFitting.jl:41
+ *   Q_total  scf_data.A   (# aux, all shards)       DensityFitting.jl:42
+ *   q0,q1    this shard's aux function range [q0,q1), 0-based
+ *            (static_load_rank_indicies, DynamicLoad.jl:174-203)
+ *   n_occ    scf_data.occ                            DensityFitting.jl:43
+ *   P        screening_data.screened_indices_count  (ScreenedDF.jl:28)
+ *   pq_p,pq_q  for packed index c: outer index p and inner index q, i.e. the
+ *            inverse of sparse_pq_index_map[q,p] (SchwarzScreening.jl:72-81;
+ *            reference builds it on device at GPUDF.jl:422-438).  Must be a
+ *            symmetric set: (q,p) kept <=> (p,q) kept.  NULL,NULL with
+ *            P == N*N selects the unscreened map c = q + N*p
+ *            (SchwarzScreening.jl:97-111) == the dense GPU path. */
+int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, int64_t q1,
+                       int64_t n_occ, int64_t P, const int64_t *pq_p, const int64_t *pq_q);
+
+/* Metric.  `J2c` = two_center_integrals (Q_total x Q_total, lower triangle
+ * valid, TwoCenterIntegrals.jl:7-29).  Performs potrf('L') + trtri('L','N')
+ * on the host (GPUDF.jl:890-891, DensityFitting.jl:137-140) and uploads the
+ * rows [q0,q1) of L^-1. */
+int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c);
+/* Same, when the caller already holds L^-1 (Q_total x Q_total, lower
+ * triangular, upper = 0) — what GPUDF.jl:893-902 uploads / broadcasts. */
+int32_t jcdf_set_metric_inverse(jcdf_handle *h, const double *Linv);
+
+/* Push the three-centre integrals of aux rows [s0,s1) (global, 0-based):
+ * T is (s1-s0) x P, column-major (ThreeCenterIntegralsScreened.jl:8-85 /
+ * ThreeCenterIntegrals.jl:9-42 with the dense map).  The library accumulates
+ *   B[q0:q1, :] += Linv[q0:q1, s0:s1] * T
+ * on the device (trmm/gemm of GPUDF.jl:907,939-943; DenseGPUDF.jl:210,270).
+ * Call once per row block, in any order, covering [0,Q_total) (blocks with
+ * s0 >= q1 contribute zero and may be skipped: L^-1 is lower triangular).
+ * The first push zeroes B. */
+int32_t jcdf_push_three_center(jcdf_handle *h, int64_t s0, int64_t s1, const double *T);
+/* Same with T already on this handle's device (e.g. received over RCCL). */
+int32_t jcdf_push_three_center_device(jcdf_handle *h, int64_t s0, int64_t s1, const double *d_T);
+/* Alternative to set_metric + push: the caller already holds this shard of
+ * B = L^-1 T ((q1-q0) x P column-major), e.g. from the reference's CPU path
+ * (ScreenedDF.jl:103). */
+int32_t jcdf_set_B(jcdf_handle *h, const double *B);
+/* Read back this shard of B in the reference layout ((q1-q0) x P col-major). */
+int32_t jcdf_get_B(jcdf_handle *h, double *B_out);
+
+/* Core Hamiltonian, N x N.  NULL: this shard adds no H (reference adds H on
+ * rank 0 / device 1 only: GPUDF.jl:221-225, DenseGPUDF.jl:114-119). */
+int32_t jcdf_set_core_hamiltonian(jcdf_handle *h, const double *H);
+
+/* ---- per SCF iteration (GPUDF.jl:188-277 / DenseGPUDF.jl:83-137) ------------- */
+/* C_occ: N x n_occ column-major (= coefficients[:,1:occ], DensityFitting.jl:49).
+ * F_out: N x N host buffer, fully overwritten with this shard's
+ * 2J - K (+ H if set) — the contract of scf_data.two_electron_fock
+ * (DensityFitting.jl:62-75).  t may be NULL. */
+int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t);
+/* Same with device pointers on this handle's device.  Work is enqueued on
+ * `stream` (a hipStream_t, NULL = the handle's own stream) and is NOT
+ * synchronised on return, so the caller can chain an RCCL all-reduce of d_F. */
+int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_F, void *stream);
+/* Blocks until work enqueued by the previous call has finished; fills timings. */
+int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t);
+
+/* Intermediates of the last build, for parity tests (reference names):
+ * V = device_coulomb_intermediate (length q1-q0); W = device_exchange_intermediate
+ * in the reference GPU layout (q1-q0, n_occ, N) column-major (GPUDF.jl:140). */
+int32_t jcdf_get_V(jcdf_handle *h, double *V_out);
+int32_t jcdf_get_W(jcdf_handle *h, double *W_out);
+
+/* Host utility used by jcdf_set_metric, exported for testing without a GPU:
+ * in-place lower Cholesky + triangular inverse of the n x n column-major matrix
+ * A (LAPACK.potrf!('L') + trtri!('L','N'), GPUDF.jl:890-891).  Returns 0, or the
+ * 1-based index of the first non-positive pivot.  Upper triangle is zeroed. */
+int32_t jcdf_host_potrf_trtri(double *A, int64_t n);
+
+/* ---- introspection ------------------------------------------------------------ */
+/* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */
+int64_t jcdf_device_bytes(const jcdf_handle *h);
+/* Per-kernel stats of the last build; returns the number of records written
+ * (<= max_records). */
+int32_t jcdf_kernel_stats(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JCDF_H */

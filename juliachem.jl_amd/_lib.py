@@ -1,0 +1,76 @@
+"""ctypes binding of libjcdf_hip.so (include/jcdf.h).  The product path has no
+CPU fallback: if the HIP library is missing or no gfx950 device exists, every
+entry point raises JCDFError."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjcdf_hip.so")
+
+
+class JCDFError(RuntimeError):
+    """A non-zero jcdf_* status, converted the way the Julia glue converts it
+    to error() (reference convention: GPUDF.jl:39-41)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__("jcdf status %d: %s" % (code, msg))
+        self.code = code
+
+
+class jcdf_timings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "non_zero_coeff_time", "W_time", "K_time", "V_time", "J_time", "density_time",
+        "H_add_time", "copy_J_time", "fock_time", "copy_time")]
+
+
+class jcdf_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("seconds", C.c_double), ("flops", C.c_double),
+                ("alg_flops", C.c_double), ("alg_bytes", C.c_double)]
+
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I64 = C.c_int64
+
+# every symbol include/jcdf.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "jcdf_create": (C.c_int32, [C.POINTER(_P), C.c_int32]),
+    "jcdf_destroy": (C.c_int32, [_P]),
+    "jcdf_last_error": (C.c_char_p, [_P]),
+    "jcdf_abi_version": (C.c_int32, []),
+    "jcdf_configure": (C.c_int32, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
+    "jcdf_set_metric": (C.c_int32, [_P, _P]),
+    "jcdf_set_metric_inverse": (C.c_int32, [_P, _P]),
+    "jcdf_push_three_center": (C.c_int32, [_P, _I64, _I64, _P]),
+    "jcdf_push_three_center_device": (C.c_int32, [_P, _I64, _I64, _P]),
+    "jcdf_set_B": (C.c_int32, [_P, _P]),
+    "jcdf_get_B": (C.c_int32, [_P, _P]),
+    "jcdf_set_core_hamiltonian": (C.c_int32, [_P, _P]),
+    "jcdf_fock_build": (C.c_int32, [_P, _P, _P, C.POINTER(jcdf_timings)]),
+    "jcdf_fock_build_device": (C.c_int32, [_P, _P, _P, _P]),
+    "jcdf_synchronize": (C.c_int32, [_P, C.POINTER(jcdf_timings)]),
+    "jcdf_get_V": (C.c_int32, [_P, _P]),
+    "jcdf_get_W": (C.c_int32, [_P, _P]),
+    "jcdf_host_potrf_trtri": (C.c_int32, [_P, _I64]),
+    "jcdf_device_bytes": (_I64, [_P]),
+    "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libjcdf_hip.so (built in-tree by build.sh / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JCDFError(-1, "HIP library not built: %s (run ./build.sh); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

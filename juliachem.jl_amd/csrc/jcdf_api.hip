@@ -1,0 +1,701 @@
+// jcdf_api.hip — C ABI (include/jcdf.h) of the MI355X DF-RHF Fock build.
+// Host-side orchestration only: buffer management, kernel launches on one HIP
+// stream, HIP-event timing.  All arithmetic of the hot path lives in
+// jcdf_kernels.hpp.  There is deliberately NO CPU fallback: without a HIP device
+// jcdf_create fails with JCDF_ERR_NO_DEVICE.
+#include "../../include/jcdf.h"
+#include "jcdf_kernels.hpp"
+#include "jcdf_host_lapack.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace jcdf;
+
+namespace {
+
+std::string g_create_error;
+
+inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct KernelRec {
+    const char *name;
+    hipEvent_t e0, e1;
+    double flops, alg_flops, alg_bytes;
+};
+
+}  // namespace
+
+struct jcdf_handle {
+    int device = -1;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // sizes
+    int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
+    int64_t Nk = 0, Np = 0;
+    int WMw = 0, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0;
+    int ntri = 0, S = 0, KS = 0;
+    int SJ = 0, QS = 0;
+    int64_t Wrows = 0;
+    bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
+    bool dense_map = true;
+
+    // device buffers
+    double *dB = nullptr, *dCpad = nullptr, *dW = nullptr, *dVpart = nullptr, *dV = nullptr;
+    double *dJpart = nullptr, *dKslab = nullptr, *dH = nullptr, *dF = nullptr, *dC = nullptr;
+    double *dLinvT = nullptr;
+    int64_t ldl = 0, linv_rows = 0;
+    int64_t *dpq_p = nullptr, *dpq_q = nullptr;
+    double *dRaw = nullptr, *dTint = nullptr;      // setup staging (chunked), freed after setup
+    int64_t stage_rows = 0;
+    int64_t bytes = 0;
+
+    // timing
+    std::vector<KernelRec> recs;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_h2d = nullptr, ev_d2h = nullptr;
+    bool timed_host_copy = false;
+    bool pending = false;
+};
+
+namespace {
+
+#define JCDF_HIP(h, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return JCDF_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+int32_t fail(jcdf_handle *h, int32_t code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+template <class T>
+int32_t dev_alloc(jcdf_handle *h, T **p, int64_t count, bool zero)
+{
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    if (e != hipSuccess) {
+        h->err = "hipMalloc(" + std::to_string(count * (int64_t)sizeof(T)) + " B): " + hipGetErrorString(e);
+        return JCDF_ERR_ALLOC;
+    }
+    h->bytes += count * (int64_t)sizeof(T);
+    if (zero) JCDF_HIP(h, hipMemsetAsync(*p, 0, (size_t)count * sizeof(T), h->stream));
+    return JCDF_OK;
+}
+
+template <class T>
+void dev_free(jcdf_handle *h, T **p, int64_t count)
+{
+    if (*p) {
+        (void)hipFree(*p);
+        h->bytes -= std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
+        *p = nullptr;
+    }
+}
+
+void free_all(jcdf_handle *h)
+{
+    (void)hipSetDevice(h->device);
+    double **bufs[] = {&h->dB, &h->dCpad, &h->dW, &h->dVpart, &h->dV, &h->dJpart, &h->dKslab,
+                       &h->dH, &h->dF, &h->dC, &h->dLinvT, &h->dRaw, &h->dTint};
+    for (auto b : bufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (h->dpq_p) { (void)hipFree(h->dpq_p); h->dpq_p = nullptr; }
+    if (h->dpq_q) { (void)hipFree(h->dpq_q); h->dpq_q = nullptr; }
+    for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    h->recs.clear();
+    h->bytes = 0;
+    h->configured = h->have_metric = h->have_B = h->have_H = h->pushed_any = false;
+}
+
+// ---- W kernel dispatch over the number of 16-orbital MFMA row tiles ---------
+template <int WM>
+void launch_W_t(jcdf_handle *h, hipStream_t st)
+{
+    using Cfg = WCfg<WM>;
+    const int64_t outer = h->Ql * h->n_ntiles;
+    const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
+    hipLaunchKernelGGL(k_exchange_W<WM>, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
+                       h->dCpad, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
+                       h->opad, h->n_mtiles, h->n_ntiles);
+}
+
+template <int WM>
+void set_W_attr_t()
+{
+    (void)hipFuncSetAttribute((const void *)k_exchange_W<WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              WCfg<WM>::SMEM_BYTES);
+}
+
+void set_W_attr(int WM)
+{
+    switch (WM) {
+        case 1: set_W_attr_t<1>(); break;
+        case 2: set_W_attr_t<2>(); break;
+        case 3: set_W_attr_t<3>(); break;
+        case 4: set_W_attr_t<4>(); break;
+        case 5: set_W_attr_t<5>(); break;
+        case 6: set_W_attr_t<6>(); break;
+        case 7: set_W_attr_t<7>(); break;
+        default: set_W_attr_t<8>(); break;
+    }
+}
+
+void launch_W(jcdf_handle *h, hipStream_t st)
+{
+    switch (h->WMw) {
+        case 1: launch_W_t<1>(h, st); break;
+        case 2: launch_W_t<2>(h, st); break;
+        case 3: launch_W_t<3>(h, st); break;
+        case 4: launch_W_t<4>(h, st); break;
+        case 5: launch_W_t<5>(h, st); break;
+        case 6: launch_W_t<6>(h, st); break;
+        case 7: launch_W_t<7>(h, st); break;
+        default: launch_W_t<8>(h, st); break;
+    }
+}
+
+KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t st)
+{
+    if (h->recs.size() <= idx) {
+        KernelRec r{};
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        h->recs.push_back(r);
+    }
+    KernelRec &r = h->recs[idx];
+    r.name = name;
+    r.flops = r.alg_flops = r.alg_bytes = 0.0;
+    (void)hipEventRecord(r.e0, st);
+    return r;
+}
+
+int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t st)
+{
+    const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o;
+    size_t k = 0;
+    (void)hipEventRecord(h->ev_begin, st);
+    {
+        KernelRec &r = rec_begin(h, k++, "k_prep_C", st);
+        const int64_t tot = h->Np * h->opad;
+        hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
+                           (int)h->o, (int)h->Np, h->opad, h->dCpad);
+        r.alg_bytes = 8.0 * N * o;
+        (void)hipEventRecord(r.e1, st);
+    }
+    {
+        KernelRec &r = rec_begin(h, k++, "k_exchange_W", st);
+        launch_W(h, st);
+        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)h->opad;
+        r.alg_flops = 2.0 * Ql * N * N * o + 2.0 * Ql * N * o;      // W (+ fused V from W)
+        r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
+        (void)hipEventRecord(r.e1, st);
+    }
+    {
+        KernelRec &r = rec_begin(h, k++, "k_coulomb_J", st);
+        hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)h->N, (unsigned)h->SJ), dim3(256),
+                           (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
+                           (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV);
+        r.flops = r.alg_flops = Ql * N * (N + 1.0);
+        r.alg_bytes = 8.0 * Ql * N * (N + 1.0) / 2.0;               // lower triangle of B, once
+        (void)hipEventRecord(r.e1, st);
+    }
+    {
+        KernelRec &r = rec_begin(h, k++, "k_exchange_K", st);
+        const int nblk = (int)(roundup(h->S, 8) * h->ntri);
+        hipLaunchKernelGGL(k_exchange_K, dim3((unsigned)nblk), dim3(KCfg::NT), KCfg::SMEM_BYTES, st, h->dW,
+                           (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
+        r.flops = 2.0 * (double)h->ntri * 128.0 * 128.0 * (double)h->S * (double)h->KS;
+        r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
+        r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
+        (void)hipEventRecord(r.e1, st);
+    }
+    {
+        KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st);
+        hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
+                           st, h->dJpart, h->SJ, h->dKslab, h->S, h->ntri, h->have_H ? h->dH : nullptr,
+                           (int)h->N, (int)h->Nk, (int)h->Np, dF);
+        r.alg_bytes = 8.0 * N * N * (h->have_H ? 2.0 : 1.0);
+        (void)hipEventRecord(r.e1, st);
+    }
+    (void)hipEventRecord(h->ev_end, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->pending = true;
+    return JCDF_OK;
+}
+
+double elapsed_s(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0;
+    return (double)ms * 1e-3;
+}
+
+int32_t ensure_stage(jcdf_handle *h, int64_t rows)
+{
+    if (h->stage_rows >= rows) return JCDF_OK;
+    dev_free(h, &h->dRaw, h->stage_rows * h->P);
+    dev_free(h, &h->dTint, roundup(h->stage_rows, KC) * h->Nk * h->Np);
+    h->stage_rows = 0;
+    int32_t rc = dev_alloc(h, &h->dRaw, rows * h->P, false);
+    if (rc) return rc;
+    rc = dev_alloc(h, &h->dTint, roundup(rows, KC) * h->Nk * h->Np, false);
+    if (rc) return rc;
+    h->stage_rows = rows;
+    return JCDF_OK;
+}
+
+void release_stage(jcdf_handle *h)
+{
+    dev_free(h, &h->dRaw, h->stage_rows * h->P);
+    dev_free(h, &h->dTint, roundup(h->stage_rows, KC) * h->Nk * h->Np);
+    h->stage_rows = 0;
+}
+
+constexpr int64_t STAGE_ROWS = 256;
+
+// scatter `rows` aux rows (raw block on device, leading dim R) into dst [rows][Nk][Np]
+void launch_scatter(jcdf_handle *h, const double *raw, int64_t R, double *dst)
+{
+    dim3 grid((unsigned)((R + 31) / 32), (unsigned)((h->P + 31) / 32));
+    hipLaunchKernelGGL(k_scatter_T, grid, dim3(256), 0, h->stream, raw, R, h->P, h->dpq_p, h->dpq_q, (int)h->N,
+                       (int)h->Nk, (int)h->Np, dst);
+}
+
+// Accumulate B += Linv[q0:q1, s0:s1] * T for one block of rows.  `T` has leading
+// dimension ldT rows (column-major (ldT x P)); on_device selects the copy kind.
+int32_t push_block(jcdf_handle *h, int64_t s0, int64_t s1, const double *T, bool on_device)
+{
+    const int64_t Rtot = s1 - s0;
+    const int64_t slab = h->Nk * h->Np;
+    for (int64_t a0 = 0; a0 < Rtot; a0 += STAGE_ROWS) {
+        const int64_t R = std::min(STAGE_ROWS, Rtot - a0);
+        int32_t rc = ensure_stage(h, STAGE_ROWS);
+        if (rc) return rc;
+        // sub-rows [a0, a0+R) of every column: 2-D copy, R*8 bytes wide, P columns
+        JCDF_HIP(h, hipMemcpy2DAsync(h->dRaw, (size_t)R * 8, T + a0, (size_t)Rtot * 8, (size_t)R * 8,
+                                     (size_t)h->P, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                     h->stream));
+        const int64_t Kpad = roundup(R, KC);
+        JCDF_HIP(h, hipMemsetAsync(h->dTint, 0, (size_t)(Kpad * slab) * 8, h->stream));
+        launch_scatter(h, h->dRaw, R, h->dTint);
+        const int n_xtiles = (int)(slab / MCfg::TN);
+        const int n_mt = (int)(roundup(h->Ql, MCfg::TM) / MCfg::TM);
+        hipLaunchKernelGGL(k_metric_apply, dim3((unsigned)(n_xtiles * n_mt)), dim3(MCfg::NT), MCfg::SMEM_BYTES,
+                           h->stream, h->dLinvT + (s0 + a0) * h->ldl, h->ldl, h->dTint, slab, (int)Kpad,
+                           (int)h->Ql, n_xtiles, h->dB);
+        if (!on_device) JCDF_HIP(h, hipStreamSynchronize(h->stream));   // host buffer may be reused by caller
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("push_block: ") + hipGetErrorString(e));
+    return JCDF_OK;
+}
+
+int32_t upload_linv(jcdf_handle *h, const double *Linv)
+{
+    // LinvT[s][r] = Linv[(q0 + r) + Qtot * s]: column s of Linv restricted to the shard's rows
+    h->ldl = roundup(h->Ql, MCfg::TM);
+    h->linv_rows = h->Qtot + 2 * KC;
+    if (!h->dLinvT) {
+        int32_t rc = dev_alloc(h, &h->dLinvT, h->linv_rows * h->ldl, true);
+        if (rc) return rc;
+    } else {
+        JCDF_HIP(h, hipMemsetAsync(h->dLinvT, 0, (size_t)(h->linv_rows * h->ldl) * 8, h->stream));
+    }
+    JCDF_HIP(h, hipMemcpy2DAsync(h->dLinvT, (size_t)h->ldl * 8, Linv + h->q0, (size_t)h->Qtot * 8,
+                                 (size_t)h->Ql * 8, (size_t)h->Qtot, hipMemcpyHostToDevice, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_metric = true;
+    return JCDF_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+int32_t jcdf_abi_version(void) { return 1000; }
+
+const char *jcdf_last_error(const jcdf_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
+{
+    if (!out) { g_create_error = "jcdf_create: out == NULL"; return JCDF_ERR_INVALID; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = "jcdf_create: no HIP device available (" +
+                         std::string(e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                         "); libjcdf_hip has no CPU fallback";
+        return JCDF_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) {
+        g_create_error = "jcdf_create: device_id " + std::to_string(device_id) + " out of range [0," +
+                         std::to_string(count) + ")";
+        return JCDF_ERR_INVALID;
+    }
+    jcdf_handle *h = new (std::nothrow) jcdf_handle();
+    if (!h) { g_create_error = "jcdf_create: out of host memory"; return JCDF_ERR_ALLOC; }
+    h->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("jcdf_create: ") + hipGetErrorString(e);
+        delete h;
+        return JCDF_ERR_HIP;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("jcdf_create: device is ") + prop.gcnArchName +
+                         ", this library contains gfx950 (MI355X) code objects only";
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        return JCDF_ERR_NO_DEVICE;
+    }
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    (void)hipEventCreate(&h->ev_begin);
+    (void)hipEventCreate(&h->ev_end);
+    (void)hipEventCreate(&h->ev_h2d);
+    (void)hipEventCreate(&h->ev_d2h);
+    (void)hipFuncSetAttribute((const void *)k_exchange_K, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              KCfg::SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void *)k_metric_apply, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MCfg::SMEM_BYTES);
+    *out = h;
+    return JCDF_OK;
+}
+
+int32_t jcdf_destroy(jcdf_handle *h)
+{
+    if (!h) return JCDF_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
+    if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return JCDF_OK;
+}
+
+int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, int64_t q1, int64_t n_occ,
+                       int64_t P, const int64_t *pq_p, const int64_t *pq_q)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (N <= 0 || Q_total <= 0 || q0 < 0 || q1 <= q0 || q1 > Q_total || n_occ <= 0 || n_occ > N || P <= 0)
+        return fail(h, JCDF_ERR_INVALID, "jcdf_configure: invalid sizes");
+    if ((pq_p == nullptr) != (pq_q == nullptr))
+        return fail(h, JCDF_ERR_INVALID, "jcdf_configure: pq_p and pq_q must both be given or both NULL");
+    if (!pq_p && P != N * N)
+        return fail(h, JCDF_ERR_INVALID, "jcdf_configure: NULL pq map requires P == N*N (dense map)");
+    if (P > N * N) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: P > N*N");
+    if (N > 46000) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: N too large for 32-bit tile indices");
+    if (pq_p) {                                        // the packed set must be symmetric and duplicate-free
+        std::vector<uint8_t> seen((size_t)(N * N), 0);
+        for (int64_t c = 0; c < P; ++c) {
+            const int64_t p = pq_p[c], q = pq_q[c];
+            if (p < 0 || p >= N || q < 0 || q >= N)
+                return fail(h, JCDF_ERR_INVALID, "jcdf_configure: pq index out of range at packed index " + std::to_string(c));
+            if (seen[(size_t)(q + N * p)]) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: duplicate pq pair");
+            seen[(size_t)(q + N * p)] = 1;
+        }
+        for (int64_t c = 0; c < P; ++c)
+            if (!seen[(size_t)(pq_p[c] + N * pq_q[c])])
+                return fail(h, JCDF_ERR_INVALID, "jcdf_configure: packed pq set is not symmetric");
+    }
+    JCDF_HIP(h, hipSetDevice(h->device));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    free_all(h);
+
+    h->N = N; h->Qtot = Q_total; h->q0 = q0; h->q1 = q1; h->Ql = q1 - q0; h->o = n_occ; h->P = P;
+    h->dense_map = (pq_p == nullptr);
+    h->Nk = roundup(N, KC);
+    h->Np = roundup(N, TILE_P);
+    h->n_ntiles = (int)(h->Np / TILE_P);
+    // orbital (M) tiling of the W kernel: <= 128 orbitals per workgroup, balanced
+    h->n_mtiles = (int)((n_occ + 127) / 128);
+    h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
+    h->opad = h->n_mtiles * h->WMw * 16;
+    h->nvp = h->n_ntiles * h->n_mtiles;
+    set_W_attr(h->WMw);
+    // K: lower block-triangle of 128x128 tiles, split-K so that one wave of workgroups fills the chip
+    const int nT = h->n_ntiles;
+    h->ntri = nT * (nT + 1) / 2;
+    const int64_t Ktot = h->Ql * h->o;
+    const int64_t max_chunks = std::max<int64_t>(1, Ktot / (8 * KC));      // >= 8 LDS stages per slice
+    int64_t S = std::max<int64_t>(1, (2 * (int64_t)h->num_cu) / h->ntri);
+    S = std::min(S, max_chunks);
+    h->KS = (int)roundup((Ktot + S - 1) / S, KC);
+    h->S = (int)((Ktot + h->KS - 1) / h->KS);
+    h->Wrows = (int64_t)h->S * h->KS;
+    // J: slices over the aux index so that ~8 blocks per CU are in flight
+    int64_t SJ = std::max<int64_t>(1, (8 * (int64_t)h->num_cu + N - 1) / N);
+    SJ = std::min<int64_t>(SJ, std::max<int64_t>(1, h->Ql / 32));
+    h->QS = (int)((h->Ql + SJ - 1) / SJ);
+    h->SJ = (int)((h->Ql + h->QS - 1) / h->QS);
+    if ((size_t)h->QS * 8 > 48 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux slice too long");
+
+    int32_t rc;
+    if ((rc = dev_alloc(h, &h->dB, h->Ql * h->Nk * h->Np, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dCpad, h->Np * h->opad, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dW, h->Wrows * h->Np, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dVpart, h->Ql * h->nvp, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dV, h->Ql, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dJpart, (int64_t)h->SJ * h->Nk * h->Np, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dKslab, (int64_t)h->S * h->ntri * 128 * 128, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dH, N * N, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dF, N * N, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dC, N * n_occ, true))) return rc;
+    if (pq_p) {
+        if ((rc = dev_alloc(h, &h->dpq_p, P, false))) return rc;
+        if ((rc = dev_alloc(h, &h->dpq_q, P, false))) return rc;
+        JCDF_HIP(h, hipMemcpyAsync(h->dpq_p, pq_p, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
+        JCDF_HIP(h, hipMemcpyAsync(h->dpq_q, pq_q, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->configured = true;
+    return JCDF_OK;
+}
+
+int32_t jcdf_set_metric_inverse(jcdf_handle *h, const double *Linv)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !Linv) return fail(h, JCDF_ERR_INVALID, "jcdf_set_metric_inverse: configure first / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    return upload_linv(h, Linv);
+}
+
+int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !J2c) return fail(h, JCDF_ERR_INVALID, "jcdf_set_metric: configure first / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    std::vector<double> L;
+    try {
+        L.assign(J2c, J2c + (size_t)(h->Qtot * h->Qtot));
+    } catch (...) {
+        return fail(h, JCDF_ERR_ALLOC, "jcdf_set_metric: out of host memory");
+    }
+    const int info = hostlapack::potrf_trtri_lower(L.data(), h->Qtot);
+    if (info != 0)
+        return fail(h, JCDF_ERR_NOT_SPD, "jcdf_set_metric: (P|Q) not positive definite at pivot " + std::to_string(info));
+    return upload_linv(h, L.data());
+}
+
+int32_t jcdf_push_three_center(jcdf_handle *h, int64_t s0, int64_t s1, const double *T)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_metric) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center: configure + set_metric first");
+    if (!T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center: bad row range");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (!h->pushed_any) {
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * h->Nk * h->Np) * 8, h->stream));
+        h->pushed_any = true;
+    }
+    if (s0 >= h->q1) return JCDF_OK;                 // Linv[q0:q1, s0:s1] == 0 (lower triangular)
+    int32_t rc = push_block(h, s0, s1, T, false);
+    if (rc) return rc;
+    h->have_B = true;
+    return JCDF_OK;
+}
+
+int32_t jcdf_push_three_center_device(jcdf_handle *h, int64_t s0, int64_t s1, const double *d_T)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_metric) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center_device: configure + set_metric first");
+    if (!d_T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center_device: bad row range");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (!h->pushed_any) {
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * h->Nk * h->Np) * 8, h->stream));
+        h->pushed_any = true;
+    }
+    if (s0 >= h->q1) return JCDF_OK;
+    int32_t rc = push_block(h, s0, s1, d_T, true);
+    if (rc) return rc;
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_B = true;
+    return JCDF_OK;
+}
+
+int32_t jcdf_set_B(jcdf_handle *h, const double *B)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !B) return fail(h, JCDF_ERR_INVALID, "jcdf_set_B: configure first / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    const int64_t slab = h->Nk * h->Np;
+    JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * slab) * 8, h->stream));
+    for (int64_t a0 = 0; a0 < h->Ql; a0 += STAGE_ROWS) {
+        const int64_t R = std::min(STAGE_ROWS, h->Ql - a0);
+        int32_t rc = ensure_stage(h, STAGE_ROWS);
+        if (rc) return rc;
+        JCDF_HIP(h, hipMemcpy2DAsync(h->dRaw, (size_t)R * 8, B + a0, (size_t)h->Ql * 8, (size_t)R * 8, (size_t)h->P,
+                                     hipMemcpyHostToDevice, h->stream));
+        launch_scatter(h, h->dRaw, R, h->dB + a0 * slab);
+        JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    release_stage(h);
+    h->have_B = true;
+    h->pushed_any = true;
+    return JCDF_OK;
+}
+
+int32_t jcdf_get_B(jcdf_handle *h, double *B_out)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_B || !B_out) return fail(h, JCDF_ERR_INVALID, "jcdf_get_B: no B yet / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    const int64_t slab = h->Nk * h->Np;
+    for (int64_t a0 = 0; a0 < h->Ql; a0 += STAGE_ROWS) {
+        const int64_t R = std::min(STAGE_ROWS, h->Ql - a0);
+        int32_t rc = ensure_stage(h, STAGE_ROWS);
+        if (rc) return rc;
+        dim3 grid((unsigned)((R + 31) / 32), (unsigned)((h->P + 31) / 32));
+        hipLaunchKernelGGL(k_gather_T, grid, dim3(256), 0, h->stream, h->dB + a0 * slab, R, h->P, h->dpq_p,
+                           h->dpq_q, (int)h->N, (int)h->Nk, (int)h->Np, h->dRaw);
+        JCDF_HIP(h, hipMemcpy2DAsync(B_out + a0, (size_t)h->Ql * 8, h->dRaw, (size_t)R * 8, (size_t)R * 8,
+                                     (size_t)h->P, hipMemcpyDeviceToHost, h->stream));
+        JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    release_stage(h);
+    return JCDF_OK;
+}
+
+int32_t jcdf_set_core_hamiltonian(jcdf_handle *h, const double *H)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured) return fail(h, JCDF_ERR_INVALID, "jcdf_set_core_hamiltonian: configure first");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (!H) { h->have_H = false; return JCDF_OK; }
+    JCDF_HIP(h, hipMemcpyAsync(h->dH, H, (size_t)(h->N * h->N) * 8, hipMemcpyHostToDevice, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_H = true;
+    return JCDF_OK;
+}
+
+int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_F, void *stream)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device: B not set");
+    if (!d_C_occ || !d_F) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device: NULL pointer");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (h->stage_rows) release_stage(h);
+    h->timed_host_copy = false;
+    return enqueue_fock(h, d_C_occ, d_F, stream ? (hipStream_t)stream : h->stream);
+}
+
+int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (h->pending) {
+        JCDF_HIP(h, hipEventSynchronize(h->ev_end));
+        h->pending = false;
+    }
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    if (t) {
+        std::memset(t, 0, sizeof(*t));
+        if (h->recs.size() >= 5) {
+            t->non_zero_coeff_time = elapsed_s(h->recs[0].e0, h->recs[0].e1);
+            t->W_time = elapsed_s(h->recs[1].e0, h->recs[1].e1);
+            t->J_time = elapsed_s(h->recs[2].e0, h->recs[2].e1);
+            t->K_time = elapsed_s(h->recs[3].e0, h->recs[3].e1);
+            t->copy_J_time = elapsed_s(h->recs[4].e0, h->recs[4].e1);
+            t->fock_time = elapsed_s(h->ev_begin, h->ev_end);
+            if (h->timed_host_copy)
+                t->copy_time = elapsed_s(h->ev_h2d, h->ev_begin) + elapsed_s(h->ev_end, h->ev_d2h);
+        }
+    }
+    return JCDF_OK;
+}
+
+int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build: B not set");
+    if (!C_occ || !F_out) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build: NULL pointer");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (h->stage_rows) release_stage(h);
+    (void)hipEventRecord(h->ev_h2d, h->stream);
+    JCDF_HIP(h, hipMemcpyAsync(h->dC, C_occ, (size_t)(h->N * h->o) * 8, hipMemcpyHostToDevice, h->stream));
+    int32_t rc = enqueue_fock(h, h->dC, h->dF, h->stream);
+    if (rc) return rc;
+    JCDF_HIP(h, hipMemcpyAsync(F_out, h->dF, (size_t)(h->N * h->N) * 8, hipMemcpyDeviceToHost, h->stream));
+    (void)hipEventRecord(h->ev_d2h, h->stream);
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->timed_host_copy = true;
+    return jcdf_synchronize(h, t);
+}
+
+int32_t jcdf_get_V(jcdf_handle *h, double *V_out)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !V_out) return fail(h, JCDF_ERR_INVALID, "jcdf_get_V: not configured / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    JCDF_HIP(h, hipMemcpy(V_out, h->dV, (size_t)h->Ql * 8, hipMemcpyDeviceToHost));
+    return JCDF_OK;
+}
+
+int32_t jcdf_get_W(jcdf_handle *h, double *W_out)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !W_out) return fail(h, JCDF_ERR_INVALID, "jcdf_get_W: not configured / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    const int64_t total = h->Ql * h->o * h->N;
+    double *tmp = nullptr;
+    int32_t rc = dev_alloc(h, &tmp, total, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_W, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->dW,
+                       (int)h->Ql, (int)h->o, (int)h->N, (int)h->Np, tmp);
+    hipError_t e = hipMemcpyAsync(W_out, tmp, (size_t)total * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dev_free(h, &tmp, total);
+    if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("jcdf_get_W: ") + hipGetErrorString(e));
+    return JCDF_OK;
+}
+
+int32_t jcdf_host_potrf_trtri(double *A, int64_t n)
+{
+    if (!A || n <= 0) return -1;
+    return hostlapack::potrf_trtri_lower(A, n);
+}
+
+int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }
+
+int32_t jcdf_kernel_stats(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records)
+{
+    if (!h || !out || max_records <= 0) return 0;
+    if (h->pending) {
+        (void)hipEventSynchronize(h->ev_end);
+        h->pending = false;
+    }
+    int32_t n = 0;
+    for (auto &r : h->recs) {
+        if (n >= max_records) break;
+        std::memset(&out[n], 0, sizeof(out[n]));
+        std::snprintf(out[n].name, sizeof(out[n].name), "%s", r.name ? r.name : "?");
+        out[n].seconds = elapsed_s(r.e0, r.e1);
+        out[n].flops = r.flops;
+        out[n].alg_flops = r.alg_flops;
+        out[n].alg_bytes = r.alg_bytes;
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

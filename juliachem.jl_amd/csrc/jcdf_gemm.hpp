@@ -1,0 +1,159 @@
+// jcdf_gemm.hpp — fp64 MFMA "TN" GEMM core for gfx950 (MI355X), shared by the
+// three MFMA kernels of the DF Fock build (W, K, metric-apply).
+//
+//   acc[m][n] += sum_k A[k][m] * B[k][n]
+//
+// Both operands are stored k-major (row k contiguous in m resp. n).  Every
+// matrix on the path is laid out so that this holds (see DESIGN.md "layout"):
+//   W pass   : A = C_occ  [q][i]      B = B_Q   [q][p]
+//   K pass   : A = W      [(Q,i)][p]  B = W     [(Q,i)][p']
+//   metric   : A = Linv^T [s][r]      B = T     [s][(q,p)]
+//
+// Hardware mapping (CDNA4): v_mfma_f64_16x16x4_f64, one f64 of A and of B per
+// lane: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]; the
+// result has col = lane&15, row = (lane>>4) + 4*reg  (NOT the f32 C/D map).
+// A workgroup owns a TM x TN output tile, TM = 16*WM*WAVES_M, TN = 16*WN*WAVES_N;
+// each 64-lane wave owns WM x WN MFMA tiles.  k is consumed in chunks of KC rows
+// staged through LDS (double buffered, one barrier per chunk).  LDS rows are
+// padded so that (row stride in bytes) % 256 == 128: the two k-rows a
+// ds_read_b64 half-wave touches then fall on disjoint bank halves
+// (conflict-free; MI355X_MICROARCH §LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jcdf {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+template <int WM_, int WN_, int WAVES_M_, int WAVES_N_, int KC_>
+struct GemmCfg {
+    static constexpr int WM = WM_, WN = WN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, KC = KC_;
+    static constexpr int TM = 16 * WM * WAVES_M;
+    static constexpr int TN = 16 * WN * WAVES_N;
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;
+    static constexpr int LDAS = TM + ((TM % 32 == 16) ? 0 : 16);   // doubles; stride*8 % 256 == 128
+    static constexpr int LDBS = TN + ((TN % 32 == 16) ? 0 : 16);
+    static constexpr int STAGE_DOUBLES = KC * (LDAS + LDBS);
+    static constexpr int SMEM_BYTES = 2 * STAGE_DOUBLES * 8;
+    static constexpr int A_VEC = KC * TM / 2;                        // double2 per A stage
+    static constexpr int B_VEC = KC * TN / 2;
+    static constexpr int A_PER_THREAD = (A_VEC + NT - 1) / NT;
+    static constexpr int B_PER_THREAD = (B_VEC + NT - 1) / NT;
+    static_assert(KC % 4 == 0, "KC must be a multiple of the MFMA k (4)");
+};
+
+// Ag -> A[k = 0][m0], Bg -> B[k = 0][n0]; lda/ldb in doubles (even, 16-B aligned rows).
+// nchunks = K / KC.  All tile loads must be in bounds (buffers are padded).
+// STREAM_B: the B operand is read exactly once from HBM by the whole grid (the
+// 3-index tensor) -> non-temporal loads keep it from evicting the reused operand.
+template <class Cfg, bool STREAM_B>
+__device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int64_t lda,
+                                             const double *__restrict__ Bg, int64_t ldb,
+                                             int nchunks, double4_t (&acc)[Cfg::WM][Cfg::WN],
+                                             double *smem)
+{
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, KC = Cfg::KC;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
+    constexpr int LDAS = Cfg::LDAS, LDBS = Cfg::LDBS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N;
+    const int wn = wave % Cfg::WAVES_N;
+    const int lr = lane & 15;   // row (A) / col (B) inside the MFMA tile
+    const int lk = lane >> 4;   // k inside the MFMA step
+
+    double2_t ra[Cfg::A_PER_THREAD];
+    double2_t rb[Cfg::B_PER_THREAD];
+
+    auto load_stage = [&](int chunk) {
+        const double *Ap = Ag + (int64_t)chunk * KC * lda;
+        const double *Bp = Bg + (int64_t)chunk * KC * ldb;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (Cfg::A_VEC % NT == 0 || idx < Cfg::A_VEC) {
+                const int r = idx / (TM / 2), c = idx % (TM / 2);
+                ra[i] = *reinterpret_cast<const double2_t *>(Ap + (int64_t)r * lda + 2 * c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::B_PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (Cfg::B_VEC % NT == 0 || idx < Cfg::B_VEC) {
+                const int r = idx / (TN / 2), c = idx % (TN / 2);
+                const double2_t *src = reinterpret_cast<const double2_t *>(Bp + (int64_t)r * ldb + 2 * c);
+                rb[i] = STREAM_B ? __builtin_nontemporal_load(src) : *src;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        double *As = smem + buf * Cfg::STAGE_DOUBLES;
+        double *Bs = As + KC * LDAS;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (Cfg::A_VEC % NT == 0 || idx < Cfg::A_VEC) {
+                const int r = idx / (TM / 2), c = idx % (TM / 2);
+                *reinterpret_cast<double2_t *>(As + r * LDAS + 2 * c) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::B_PER_THREAD; ++i) {
+            const int idx = tid + i * NT;
+            if (Cfg::B_VEC % NT == 0 || idx < Cfg::B_VEC) {
+                const int r = idx / (TN / 2), c = idx % (TN / 2);
+                *reinterpret_cast<double2_t *>(Bs + r * LDBS + 2 * c) = rb[i];
+            }
+        }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < nchunks; ++t) {
+        const bool more = (t + 1 < nchunks);
+        if (more) load_stage(t + 1);          // HBM/L2 latency hides under this chunk's MFMAs
+
+        const double *As = smem + cur * Cfg::STAGE_DOUBLES + wm * (WM * 16) + lr;
+        const double *Bs = smem + cur * Cfg::STAGE_DOUBLES + KC * LDAS + wn * (WN * 16) + lr;
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double a[WM], b[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) a[m] = As[(ks * 4 + lk) * LDAS + m * 16];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) b[n] = Bs[(ks * 4 + lk) * LDBS + n * 16];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+
+        if (more) store_stage(cur ^ 1);       // other buffer: last read before the previous barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// Element coordinates of acc[m][n][j] inside the workgroup tile.
+template <class Cfg>
+__device__ __forceinline__ int tile_row(int m, int j)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave / Cfg::WAVES_N) * (Cfg::WM * 16) + m * 16 + (lane >> 4) + 4 * j;
+}
+template <class Cfg>
+__device__ __forceinline__ int tile_col(int n)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave % Cfg::WAVES_N) * (Cfg::WN * 16) + n * 16 + (lane & 15);
+}
+
+}  // namespace jcdf

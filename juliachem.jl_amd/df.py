@@ -1,0 +1,669 @@
+"""Host-side mirror of JuliaChem's DF Fock-build operator interface, on top of the
+C ABI (include/jcdf.h).  Julia is not available in this image, so the host side
+is Python; names, argument meaning and error behaviour follow the reference so
+the parity tests read like the reference's own drivers:
+
+    df_rhf_fock_build!      DensityFitting.jl:23-76    -> df_rhf_fock_build
+    run_gpu_fock_build!     DensityFitting.jl:78-90    -> run_gpu_fock_build
+    df_rhf_fock_build_GPU!  GPUDF.jl:11-304            -> df_rhf_fock_build_GPU
+    calculate_B_GPU!        GPUDF.jl:828-1008          -> calculate_B_GPU
+    SCFData / ScreeningData shared/SCFData.jl:1-44
+    SCFGPUData_cuda         shared/GPUData_cuda.jl:4-38 -> SCFGPUData_hip
+    SCFOptions              shared/SCFOptions.jl:2-139
+    JCTiming / JCTC keys    shared/JCTiming.jl:3-145
+
+(paths relative to /root/reference/src/rhf/energy/DensityFitting/ or src/shared/).
+The Julia glue with the same structure is julia/JCDFHip.jl.
+
+This module never imports oracle/: all arithmetic happens in libjcdf_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import JCDFError, jcdf_kernel_stat, jcdf_timings
+
+
+# --------------------------------------------------------------------------
+# JCTiming (shared/JCTiming.jl)
+# --------------------------------------------------------------------------
+class JCTC:
+    """Timing-key constants, same strings as module JCTC (JCTiming.jl:3-109)."""
+    fock_time = "fock_time-"
+    iteration_time = "iteration_time-"
+    form_J_AB_inv_time = "form_J_AB_inv_time"
+    density_time = "density_time-"
+    H_add_time = "H_add_time-"
+    K_time = "K_time-"
+    W_time = "W_time-"
+    J_time = "J_time-"
+    V_time = "V_time-"
+    screening_time = "screening_time"
+    fock_MPI_time = "fock_MPI_time-"
+    contraction_algorithm = "contraction_algorithm"
+    B_time = "B_time"
+    three_eri_time = "three_eri_time"
+    two_eri_time = "two_eri_time"
+    screened_indices_count = "screened_indices_count"
+    GPU_num_devices = "GPU_num_devices"
+    GPU_data_size_MB = "GPU_-N-_data_size_MB"
+    GPU_density_time = "GPU_-N-_density_time-"
+    GPU_V_time = "GPU_-N-_V_time-"
+    GPU_J_time = "GPU_-N-_J_time-"
+    GPU_W_time = "GPU_-N-_W_time-"
+    GPU_K_time = "GPU_-N-_K_time-"
+    GPU_non_zero_coeff_time = "GPU_-N-_non_zero_coeff_time-"
+    GPU_H_add_time = "GPU_-N-_H_add_time-"
+    gpu_fock_time = "GPU_-N-_fock_time-"
+    gpu_copy_J_time = "gpu_copy_J_time-"
+    gpu_copy_sym_time = "gpu_copy_sym_time-"
+    total_fock_gpu_time = "total_fock_gpu_time-"
+    fock_gpu_cpu_copy_reduce_time = "fock_gpu_cpu_copy_reduce_time-"
+
+
+def JCTiming_key(key: str, iteration: int) -> str:
+    return key + str(iteration)                                   # JCTiming.jl:135-137
+
+
+def JCTiming_GPUkey(key: str, device: int, iteration: Optional[int] = None) -> str:
+    k = key.replace("-N-", str(device))                           # JCTiming.jl:139-145
+    return k if iteration is None else k + str(iteration)
+
+
+@dataclass
+class JCTiming:
+    run_time: float = 0.0
+    run_name: str = ""
+    converged: bool = False
+    scf_energy: float = 0.0
+    non_timing_data: Dict[str, str] = field(default_factory=dict)
+    user_options: Dict[str, str] = field(default_factory=dict)
+    options: Dict[str, str] = field(default_factory=dict)
+    timings: Dict[str, float] = field(default_factory=dict)
+
+
+def create_jctiming() -> JCTiming:
+    return JCTiming()
+
+
+# --------------------------------------------------------------------------
+# SCFOptions (shared/SCFOptions.jl, shared/Constants.jl)
+# --------------------------------------------------------------------------
+@dataclass
+class SCFOptions:
+    density_fitting: bool = False
+    contraction_mode: str = "default"
+    load: str = "static"
+    guess: str = "hcore"
+    energy_convergence: float = 1e-3
+    density_convergence: float = 1e-3
+    df_energy_convergence: float = 1e-3
+    df_density_convergence: float = 1e-3
+    max_iterations: int = 10
+    df_max_iterations: int = 10
+    df_exchange_n_blocks: int = 0
+    df_screening_sigma: float = 1e-5
+    df_screen_exchange: bool = False
+    df_force_dense: bool = False
+    df_use_adaptive: bool = True
+    num_devices: int = 1
+    df_use_K_sym: bool = False
+    df_K_sym_type: str = "square"
+
+
+def create_scf_options(scf_flags: Dict[str, Any]) -> SCFOptions:
+    """JSON keywords.scf -> SCFOptions with the reference's defaults and its
+    df_* aliasing rules (SCFOptions.jl:47-139, Constants.jl:3-78)."""
+    g = scf_flags.get
+    guess = g("guess", "hcore")
+    do_df = str(g("scf_type", "rhf")).lower() == "df"
+    dele = g("dele", 1e-3)
+    rmsd = g("rmsd", 1e-3)
+    if guess == "df":
+        df_dele, df_rmsd = g("df_dele", 1e-3), g("df_rmsd", 1e-3)
+    else:
+        df_dele, df_rmsd = dele, rmsd
+    niter = int(g("niter", 10))
+    df_niter = niter if do_df else (int(g("df_niter", 10)) if guess == "df" else 0)
+    return SCFOptions(do_df, g("contraction_mode", "default"), g("load", "static"), guess,
+                      dele, rmsd, df_dele, df_rmsd, niter, df_niter,
+                      int(g("df_exchange_n_blocks", 0)), float(g("df_sigma", 1e-5)),
+                      bool(g("df_exchange_screen", False)), bool(g("df_force_dense", False)),
+                      bool(g("df_use_adaptive", True)), int(g("num_devices", 1)),
+                      bool(g("df_use_K_sym", False)), g("df_K_sym_type", "square"))
+
+
+# --------------------------------------------------------------------------
+# data structures the path keeps (modules/BasisStructs.jl, shared/SCFData.jl)
+# --------------------------------------------------------------------------
+@dataclass
+class Shell:
+    """The fields of Shell the DF path reads (BasisStructs.jl:3-29): `pos` is the
+    1-based index of the shell's first basis function, `nbas` its Cartesian count."""
+    pos: int
+    nbas: int
+
+
+@dataclass
+class Basis:
+    """BasisStructs.jl:170-180: shells, norb (# functions), nels (# electrons)."""
+    shells: List[Shell]
+    norb: int
+    nels: int = 0
+
+    def __len__(self) -> int:
+        return len(self.shells)
+
+    def __getitem__(self, i: int) -> Shell:
+        return self.shells[i]
+
+
+def basis_from_shell_sizes(nbas: Sequence[int], nels: int = 0) -> Basis:
+    shells, pos = [], 1
+    for n in nbas:
+        shells.append(Shell(pos, int(n)))
+        pos += int(n)
+    return Basis(shells, pos - 1, nels)
+
+
+@dataclass
+class CalculationBasisSets:
+    """BasisStructs.jl:182-185 (field name `auxillary` spelled as in the reference)."""
+    primary: Basis
+    auxillary: Basis
+
+
+@dataclass
+class ScreeningData:
+    """shared/SCFData.jl:1-17, 0-based.  sparse_pq_index_map[q, p] = packed index
+    or -1 (reference: 1-based with 0 for screened)."""
+    sparse_pq_index_map: Optional[np.ndarray] = None
+    basis_function_screen_matrix: Optional[np.ndarray] = None
+    sparse_p_start_indices: Optional[np.ndarray] = None
+    non_screened_p_indices_count: Optional[np.ndarray] = None
+    screened_indices_count: int = 0
+    K_block_width: int = 0
+
+
+class SCFGPUData:
+    """abstract parent (shared/GPUData.jl:4)."""
+
+
+class SCFGPUDataNoGPU(SCFGPUData):
+    pass
+
+
+class SCFGPUData_hip(SCFGPUData):
+    """Counterpart of SCFGPUData_cuda (GPUData_cuda.jl:4-38): instead of ~30
+    CuArrays it owns opaque jcdf handles, one per device of this process."""
+
+    def __init__(self) -> None:
+        self.handles: List["JCDFHandle"] = []
+        self.device_Q_range_lengths: List[int] = []
+        self.device_Q_indices: List[range] = []
+        self.number_of_devices_used: int = 0
+
+    def close(self) -> None:
+        for h in self.handles:
+            h.close()
+        self.handles = []
+
+
+def get_default_gpu_data_hip() -> SCFGPUData_hip:
+    return SCFGPUData_hip()
+
+
+@dataclass
+class SCFData:
+    """shared/SCFData.jl:19-37 — only the fields the GPU DF path touches."""
+    gpu_data: SCFGPUData
+    two_electron_fock: Optional[np.ndarray] = None
+    screening_data: ScreeningData = field(default_factory=ScreeningData)
+    mu: int = 0          # reference field is `μ`
+    occ: int = 0
+    A: int = 0
+    scf_iteration: int = 0
+
+
+# --------------------------------------------------------------------------
+# shard + packing rules (host logic; also declared in include/jcdf.h comments)
+# --------------------------------------------------------------------------
+def get_df_static_shell_indices(basis_sets: CalculationBasisSets, n_ranks: int, rank: int) -> range:
+    """DynamicLoad.jl:160-171 (0-based half-open)."""
+    n_shells = len(basis_sets.auxillary)
+    n_indices = n_shells // n_ranks
+    begin = n_indices * rank
+    end = n_shells if rank == n_ranks - 1 else begin + n_indices
+    return range(begin, end)
+
+
+def static_load_rank_indicies(rank: int, n_ranks: int, basis_sets: CalculationBasisSets
+                              ) -> Tuple[range, range]:
+    """(aux shell range, aux function range), 0-based half-open (DynamicLoad.jl:174-203)."""
+    sh = get_df_static_shell_indices(basis_sets, n_ranks, rank)
+    aux = basis_sets.auxillary
+    if len(sh) == 0:
+        return sh, range(0, 0)
+    first = aux[sh.start].pos - 1
+    last = aux[sh.stop - 1].pos - 1 + aux[sh.stop - 1].nbas
+    return sh, range(first, last)
+
+
+def calculate_device_ranges_GPU(num_devices: int, n_ranks: int, basis_sets: CalculationBasisSets
+                                ) -> List[range]:
+    """aux function range per global device id = rank*num_devices + dev (GPUDF.jl:1026-1056)."""
+    total = num_devices * n_ranks
+    return [static_load_rank_indicies(g, total, basis_sets)[1] for g in range(total)]
+
+
+def sparse_pq_index_map_from_mask(mask: np.ndarray) -> Tuple[np.ndarray, int]:
+    """SchwarzScreening.jl:72-81: running index, outer loop p, inner loop q, at map[q, p]."""
+    keep_q, keep_p = np.nonzero(np.asarray(mask, dtype=bool))           # row = q, col = p
+    order = np.lexsort((keep_q, keep_p))                                   # sort by p, then q
+    mp = -np.ones(mask.shape, dtype=np.int64)
+    mp[keep_q[order], keep_p[order]] = np.arange(order.size)
+    return mp, int(order.size)
+
+
+def setup_unscreened_screening_matricies(n: int) -> ScreeningData:
+    """SchwarzScreening.jl:97-111: map[q, p] = q + N*p."""
+    mask = np.ones((n, n), dtype=bool)
+    mp = (np.arange(n)[:, None] + n * np.arange(n)[None, :]).astype(np.int64)
+    return ScreeningData(mp, mask, n * np.arange(n, dtype=np.int64),
+                         np.full(n, n, dtype=np.int64), n * n, 0)
+
+
+def get_screening_metadata(mask: np.ndarray) -> ScreeningData:
+    """ScreenedDF.jl:16-77 given the Schwarz keep-mask (SchwarzScreening.jl:9-71
+    needs 4-centre integrals and stays with the host integral code)."""
+    mask = np.asarray(mask, dtype=bool)
+    if mask.ndim != 2 or mask.shape[0] != mask.shape[1] or not np.array_equal(mask, mask.T):
+        raise ValueError("basis_function_screen_matrix must be square and symmetric")
+    mp, count = sparse_pq_index_map_from_mask(mask)
+    n = mask.shape[0]
+    kp = mask.sum(axis=0).astype(np.int64)
+    start = np.zeros(n, dtype=np.int64)
+    for p in range(n):
+        col = mp[:, p]
+        kept = col[col >= 0]
+        start[p] = kept[0] if kept.size else 0
+    return ScreeningData(mp, mask, start, kp, count, 0)
+
+
+def packed_pq_lists(sd: ScreeningData) -> Tuple[np.ndarray, np.ndarray]:
+    """inverse of sparse_pq_index_map: (pq_p, pq_q) per packed index
+    (create_sparse_to_p_q_kernel, GPUDF.jl:422-438)."""
+    qq, pp = np.nonzero(sd.sparse_pq_index_map >= 0)
+    idx = sd.sparse_pq_index_map[qq, pp]
+    pq_p = np.empty(sd.screened_indices_count, dtype=np.int64)
+    pq_q = np.empty(sd.screened_indices_count, dtype=np.int64)
+    pq_p[idx] = pp
+    pq_q[idx] = qq
+    return pq_p, pq_q
+
+
+# --------------------------------------------------------------------------
+# thin OO wrapper of one jcdf handle
+# --------------------------------------------------------------------------
+def _f64(a: np.ndarray, order: str = "F") -> np.ndarray:
+    return np.require(a, dtype=np.float64, requirements=["F" if order == "F" else "C", "A"])
+
+
+class JCDFHandle:
+    """One HIP device == one aux shard (include/jcdf.h)."""
+
+    def __init__(self, device_id: int = 0) -> None:
+        self._lib = _lib.load()
+        hp = C.c_void_p()
+        rc = self._lib.jcdf_create(C.byref(hp), int(device_id))
+        if rc != 0:
+            raise JCDFError(rc, (self._lib.jcdf_last_error(None) or b"").decode())
+        self._h = hp
+        self.device_id = device_id
+        self.N = self.o = self.Ql = self.P = 0
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise JCDFError(rc, (self._lib.jcdf_last_error(self._h) or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.jcdf_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, N: int, Q_total: int, q0: int, q1: int, n_occ: int,
+                  pq_p: Optional[np.ndarray] = None, pq_q: Optional[np.ndarray] = None) -> None:
+        if pq_p is None:
+            P, pp, pq = N * N, None, None
+        else:
+            self._pq_p = np.ascontiguousarray(pq_p, dtype=np.int64)
+            self._pq_q = np.ascontiguousarray(pq_q, dtype=np.int64)
+            P, pp, pq = self._pq_p.size, self._pq_p.ctypes.data, self._pq_q.ctypes.data
+        self._check(self._lib.jcdf_configure(self._h, N, Q_total, q0, q1, n_occ, P, pp, pq))
+        self.N, self.o, self.Ql, self.P, self.Qtot, self.q0, self.q1 = N, n_occ, q1 - q0, P, Q_total, q0, q1
+
+    def set_metric(self, J2c: np.ndarray) -> None:
+        a = _f64(J2c)
+        assert a.shape == (self.Qtot, self.Qtot)
+        self._check(self._lib.jcdf_set_metric(self._h, a.ctypes.data))
+
+    def set_metric_inverse(self, Linv: np.ndarray) -> None:
+        a = _f64(Linv)
+        assert a.shape == (self.Qtot, self.Qtot)
+        self._check(self._lib.jcdf_set_metric_inverse(self._h, a.ctypes.data))
+
+    def push_three_center(self, s0: int, s1: int, T: np.ndarray) -> None:
+        a = _f64(T)
+        assert a.shape == (s1 - s0, self.P), (a.shape, (s1 - s0, self.P))
+        self._check(self._lib.jcdf_push_three_center(self._h, s0, s1, a.ctypes.data))
+
+    def push_three_center_device(self, s0: int, s1: int, d_ptr: int) -> None:
+        self._check(self._lib.jcdf_push_three_center_device(self._h, s0, s1, d_ptr))
+
+    def set_B(self, B: np.ndarray) -> None:
+        a = _f64(B)
+        assert a.shape == (self.Ql, self.P)
+        self._check(self._lib.jcdf_set_B(self._h, a.ctypes.data))
+
+    def get_B(self) -> np.ndarray:
+        out = np.empty((self.Ql, self.P), dtype=np.float64, order="F")
+        self._check(self._lib.jcdf_get_B(self._h, out.ctypes.data))
+        return out
+
+    def set_core_hamiltonian(self, H: Optional[np.ndarray]) -> None:
+        if H is None:
+            self._check(self._lib.jcdf_set_core_hamiltonian(self._h, None))
+        else:
+            a = _f64(H)
+            assert a.shape == (self.N, self.N)
+            self._check(self._lib.jcdf_set_core_hamiltonian(self._h, a.ctypes.data))
+
+    def fock_build(self, C_occ: np.ndarray) -> Tuple[np.ndarray, jcdf_timings]:
+        c = _f64(C_occ)
+        assert c.shape == (self.N, self.o), (c.shape, (self.N, self.o))
+        F = np.empty((self.N, self.N), dtype=np.float64, order="F")
+        t = jcdf_timings()
+        self._check(self._lib.jcdf_fock_build(self._h, c.ctypes.data, F.ctypes.data, C.byref(t)))
+        return F, t
+
+    def fock_build_device(self, d_C_occ: int, d_F: int, stream: int = 0) -> None:
+        self._check(self._lib.jcdf_fock_build_device(self._h, d_C_occ, d_F, stream or None))
+
+    def synchronize(self) -> jcdf_timings:
+        t = jcdf_timings()
+        self._check(self._lib.jcdf_synchronize(self._h, C.byref(t)))
+        return t
+
+    def get_V(self) -> np.ndarray:
+        out = np.empty(self.Ql, dtype=np.float64)
+        self._check(self._lib.jcdf_get_V(self._h, out.ctypes.data))
+        return out
+
+    def get_W(self) -> np.ndarray:
+        out = np.empty((self.Ql, self.o, self.N), dtype=np.float64, order="F")
+        self._check(self._lib.jcdf_get_W(self._h, out.ctypes.data))
+        return out
+
+    def device_bytes(self) -> int:
+        return int(self._lib.jcdf_device_bytes(self._h))
+
+    def kernel_stats(self) -> List[Dict[str, Any]]:
+        arr = (jcdf_kernel_stat * 16)()
+        n = self._lib.jcdf_kernel_stats(self._h, arr, 16)
+        return [dict(name=arr[i].name.decode(), seconds=arr[i].seconds, flops=arr[i].flops,
+                     alg_flops=arr[i].alg_flops, alg_bytes=arr[i].alg_bytes) for i in range(n)]
+
+
+def host_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
+    """L^-1 via the library's host Cholesky/inverse (GPUDF.jl:890-891)."""
+    a = np.array(J2c, dtype=np.float64, order="F", copy=True)
+    rc = _lib.load().jcdf_host_potrf_trtri(a.ctypes.data, a.shape[0])
+    if rc != 0:
+        raise JCDFError(5, "metric not positive definite at pivot %d" % rc)
+    return a
+
+
+# --------------------------------------------------------------------------
+# integral source: what the reference gets from the JERI/Libint engines
+# (jeri_engine_thread_df, jeri_engine_thread).  Integrals stay on the host.
+# --------------------------------------------------------------------------
+class DFIntegralEngine:
+    """Host provider of the DF integrals, standing where `jeri_engine_thread_df`
+    stands in the reference signatures.  Subclasses implement:
+
+    calculate_two_center_intgrals() -> (A, A) lower triangle valid
+        (TwoCenterIntegrals.jl:7-29)
+    calculate_three_center_integrals(aux_range, screening_data) -> (len, P)
+        packed exactly like ThreeCenterIntegralsScreened.jl:8-85
+    schwarz_mask(sigma, max_P_P) -> bool (N, N) or None for "keep all"
+        (SchwarzScreening.jl:9-71)
+    """
+
+    def calculate_two_center_intgrals(self) -> np.ndarray:
+        raise NotImplementedError
+
+    def calculate_three_center_integrals(self, aux_range: range, sd: ScreeningData) -> np.ndarray:
+        raise NotImplementedError
+
+    def schwarz_mask(self, sigma: float, max_P_P: float) -> Optional[np.ndarray]:
+        return None
+
+
+class TensorIntegralEngine(DFIntegralEngine):
+    """Integrals already in memory: J2c (A,A) and dense T (A,N,N) — used with
+    synthetic tensors and with the small host integral code of the tests."""
+
+    def __init__(self, J2c: np.ndarray, T_dense: np.ndarray, mask: Optional[np.ndarray] = None):
+        self.J2c, self.T, self.mask = J2c, T_dense, mask
+
+    def calculate_two_center_intgrals(self) -> np.ndarray:
+        return np.tril(self.J2c)
+
+    def calculate_three_center_integrals(self, aux_range: range, sd: ScreeningData) -> np.ndarray:
+        pq_p, pq_q = packed_pq_lists(sd)
+        return np.asfortranarray(self.T[aux_range.start:aux_range.stop][:, pq_q, pq_p])
+
+    def schwarz_mask(self, sigma: float, max_P_P: float) -> Optional[np.ndarray]:
+        return self.mask
+
+
+# --------------------------------------------------------------------------
+# communicator shim: torch.distributed when initialised, else single rank
+# (reference: MPI.COMM_WORLD)
+# --------------------------------------------------------------------------
+def _comm() -> Tuple[int, int, Any]:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), dist
+    except Exception:
+        pass
+    return 0, 1, None
+
+
+# --------------------------------------------------------------------------
+# the operator
+# --------------------------------------------------------------------------
+def calculate_B_GPU(scf_data: SCFData, engine: DFIntegralEngine, two_center_integrals: np.ndarray,
+                    num_devices: int, basis_sets: CalculationBasisSets, jc_timing: JCTiming) -> None:
+    """B = L^-1 (Q|pq) on the devices (GPUDF.jl:828-1008).  potrf/trtri on the
+    host (:890-891); every T row block s is produced by its owner and pushed to
+    every handle r with rows_r >= rows_s (L^-1 lower triangular);
+    across processes the block travels by broadcast (reference: host-staged
+    MPI.Send/Recv!, :918-997)."""
+    rank, n_ranks, dist = _comm()
+    gd: SCFGPUData_hip = scf_data.gpu_data
+    ranges = calculate_device_ranges_GPU(num_devices, n_ranks, basis_sets)
+    gd.device_Q_indices = ranges
+    gd.device_Q_range_lengths = [len(r) for r in ranges]
+    t0 = time.perf_counter()
+    Linv = host_potrf_trtri(two_center_integrals)
+    jc_timing.timings[JCTC.form_J_AB_inv_time] = time.perf_counter() - t0
+    for h in gd.handles:
+        h.set_metric_inverse(Linv)
+    t_eri = 0.0
+    t0 = time.perf_counter()
+    for g, rows in enumerate(ranges):
+        owner, dev = divmod(g, num_devices)
+        if len(rows) == 0:
+            continue
+        T = None
+        if owner == rank:
+            t1 = time.perf_counter()
+            T = engine.calculate_three_center_integrals(rows, scf_data.screening_data)
+            t_eri += time.perf_counter() - t1
+        if n_ranks > 1:
+            import torch
+            buf = torch.empty((len(rows) * scf_data.screening_data.screened_indices_count,),
+                              dtype=torch.float64) if T is None else torch.from_numpy(
+                np.asfortranarray(T).reshape(-1, order="F").copy())
+            dev_t = _bcast_tensor(buf, owner, dist)
+            T = dev_t.numpy().reshape((len(rows), -1), order="F")
+        for h in gd.handles:
+            h.push_three_center(rows.start, rows.stop, T)
+    jc_timing.timings[JCTC.B_time] = time.perf_counter() - t0 - t_eri
+    jc_timing.timings[JCTC.three_eri_time] = t_eri
+
+
+def _bcast_tensor(buf, src: int, dist):
+    """Broadcast a CPU tensor; with the nccl (= RCCL) backend it is staged through
+    this rank's device, with gloo it stays on the host."""
+    import torch
+    if dist.get_backend() == "nccl":
+        d = buf.cuda()
+        dist.broadcast(d, src)
+        return d.cpu()
+    dist.broadcast(buf, src)
+    return buf
+
+
+def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEngine,
+                          jeri_engine_thread: Any, basis_sets: CalculationBasisSets,
+                          occupied_orbital_coefficients: np.ndarray, iteration: int,
+                          scf_options: SCFOptions, H: np.ndarray, jc_timing: JCTiming,
+                          force_dense: bool = False) -> None:
+    """Signature and side effects of df_rhf_fock_build_GPU! (GPUDF.jl:11-14):
+    scf_data.two_electron_fock <- this process's sum over its devices of
+    2J - K (+ H on rank 0, device 1)."""
+    rank, n_ranks, _ = _comm()
+    num_devices = scf_options.num_devices
+    gd = scf_data.gpu_data
+    if not isinstance(gd, SCFGPUData_hip):
+        raise JCDFError(1, "contraction_mode requires scf_data.gpu_data::SCFGPUData_hip")
+    gd.number_of_devices_used = num_devices
+    n, n_occ = scf_data.mu, scf_data.occ
+    if iteration == 1:
+        eng = jeri_engine_thread_df
+        t0 = time.perf_counter()
+        two_center = eng.calculate_two_center_intgrals()
+        jc_timing.timings[JCTC.two_eri_time] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mask = None if force_dense else eng.schwarz_mask(
+            scf_options.df_screening_sigma, float(np.max(np.abs(np.diag(two_center)))))
+        sd = setup_unscreened_screening_matricies(n) if mask is None else get_screening_metadata(mask)
+        scf_data.screening_data = sd
+        jc_timing.timings[JCTC.screening_time] = time.perf_counter() - t0
+        jc_timing.timings[JCTC.screened_indices_count] = sd.screened_indices_count
+        ranges = calculate_device_ranges_GPU(num_devices, n_ranks, basis_sets)
+        pq = (None, None) if mask is None else packed_pq_lists(sd)
+        gd.close()
+        for dev in range(num_devices):
+            rows = ranges[rank * num_devices + dev]
+            if len(rows) == 0:
+                raise JCDFError(1, "more devices than auxiliary shells: empty shard")
+            h = JCDFHandle(dev if n_ranks == 1 else _local_device(dev, num_devices))
+            h.configure(n, scf_data.A, rows.start, rows.stop, n_occ, pq[0], pq[1])
+            h.set_core_hamiltonian(H if (rank == 0 and dev == 0) else None)   # GPUDF.jl:158-161
+            gd.handles.append(h)
+        calculate_B_GPU(scf_data, eng, two_center, num_devices, basis_sets, jc_timing)
+        jc_timing.non_timing_data[JCTC.contraction_algorithm] = "dense hip" if mask is None else "screened hip"
+        jc_timing.non_timing_data[JCTC.GPU_num_devices] = str(num_devices)
+        for dev, h in enumerate(gd.handles):
+            jc_timing.non_timing_data[JCTiming_GPUkey(JCTC.GPU_data_size_MB, dev + 1)] = str(h.device_bytes() / 1024 ** 2)
+
+    t0 = time.perf_counter()
+    total = None
+    per_dev: List[jcdf_timings] = []
+    for h in gd.handles:                       # devices of this process; kernels of one handle are async
+        F, t = h.fock_build(occupied_orbital_coefficients)
+        per_dev.append(t)
+        total = F if total is None else total + F          # host reduce over devices, GPUDF.jl:273-276
+    scf_data.two_electron_fock = total
+    jc_timing.timings[JCTiming_key(JCTC.total_fock_gpu_time, iteration)] = time.perf_counter() - t0
+    for dev, t in enumerate(per_dev, start=1):
+        for key, val in ((JCTC.GPU_W_time, t.W_time), (JCTC.GPU_V_time, t.V_time), (JCTC.GPU_J_time, t.J_time),
+                         (JCTC.GPU_K_time, t.K_time), (JCTC.GPU_density_time, t.density_time),
+                         (JCTC.gpu_fock_time, t.fock_time),
+                         (JCTC.GPU_non_zero_coeff_time, t.non_zero_coeff_time)):
+            jc_timing.timings[JCTiming_GPUkey(key, dev, iteration)] = val
+        jc_timing.timings[JCTiming_GPUkey(JCTC.gpu_copy_J_time, dev, iteration)] = t.copy_J_time
+    for key, attr in ((JCTC.K_time, "K_time"), (JCTC.W_time, "W_time"), (JCTC.V_time, "V_time"),
+                      (JCTC.J_time, "J_time"), (JCTC.fock_time, "fock_time")):
+        jc_timing.timings[JCTiming_key(key, iteration)] = max(getattr(t, attr) for t in per_dev)
+    jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_H_add_time, 1, iteration)] = per_dev[0].H_add_time
+    jc_timing.timings[JCTiming_key(JCTC.fock_gpu_cpu_copy_reduce_time, iteration)] = max(t.copy_time for t in per_dev)
+
+
+def _local_device(dev: int, num_devices: int) -> int:
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0")) * num_devices + dev
+
+
+def run_gpu_fock_build(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
+                       occupied_orbital_coefficients, iteration, scf_options, H, jc_timing) -> None:
+    """DensityFitting.jl:78-90.  The reference picks its dense kernel set when
+    df_force_dense / denseGPU, or adaptively for N < 800 on one rank; here "dense"
+    only means the unscreened pq map — the same kernels run either way."""
+    rank, n_ranks, _ = _comm()
+    force_dense = scf_options.df_force_dense or scf_options.contraction_mode == "denseGPU"
+    adaptive_dense = scf_options.df_use_adaptive and scf_data.mu < 800 and rank == 0 and n_ranks == 1
+    df_rhf_fock_build_GPU(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
+                          occupied_orbital_coefficients, iteration, scf_options, H, jc_timing,
+                          force_dense=force_dense or adaptive_dense)
+
+
+def df_rhf_fock_build(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEngine, jeri_engine_thread: Any,
+                      basis_sets: CalculationBasisSets, coefficients: np.ndarray, iteration: int,
+                      scf_options: SCFOptions, H: np.ndarray, jc_timing: JCTiming) -> np.ndarray:
+    """df_rhf_fock_build! (DensityFitting.jl:23-76): returns the full Fock matrix
+    F = H + 2J - K reduced over all shards; the returned array IS
+    scf_data.two_electron_fock (the caller's DIIS mutates it in place)."""
+    rank, n_ranks, dist = _comm()
+    if iteration == 1:
+        scf_data.mu = basis_sets.primary.norb
+        scf_data.A = basis_sets.auxillary.norb
+        scf_data.occ = int(basis_sets.primary.nels) // 2
+        scf_data.two_electron_fock = np.zeros((scf_data.mu, scf_data.mu), order="F")
+    occupied_orbital_coefficients = np.asfortranarray(coefficients[:, :scf_data.occ])
+    if scf_options.contraction_mode in ("GPU", "denseGPU", "HIP"):
+        run_gpu_fock_build(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
+                           occupied_orbital_coefficients, iteration, scf_options, H, jc_timing)
+    else:
+        raise JCDFError(1, "contraction_mode %r is a CPU mode of the reference; this package only "
+                           "provides the GPU path (GPU / denseGPU / HIP) and has no CPU fallback"
+                        % scf_options.contraction_mode)
+    if n_ranks > 1:                                               # DensityFitting.jl:68-71
+        import torch
+        t0 = time.perf_counter()
+        Ft = torch.from_numpy(np.ascontiguousarray(scf_data.two_electron_fock))
+        if dist.get_backend() == "nccl":
+            d = Ft.cuda()
+            dist.all_reduce(d)
+            Ft = d.cpu()
+        else:
+            dist.all_reduce(Ft)
+        scf_data.two_electron_fock = np.asfortranarray(Ft.numpy())
+        jc_timing.timings[JCTiming_key(JCTC.fock_MPI_time, iteration)] = time.perf_counter() - t0
+    return scf_data.two_electron_fock

@@ -1,0 +1,87 @@
+"""Seeded synthetic inputs of the exact shapes of the metric configs
+(SURVEY.md 8d): the reference cannot produce real integrals in this image
+(no Julia/Libint, basis blobs missing), so benches and large tests run on
+synthetic tensors; same seed -> same bits on every box."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+SEED = 20241024
+
+# name -> (N AO, Q aux, n_occ)   SURVEY.md 8 size table
+CONFIGS = {
+    "water": (25, 96, 5),
+    "benzene_dimer": (240, 972, 42),
+    "C20H42": (510, 1950, 81),
+    "w50": (1250, 4800, 250),
+    "gly10_vtz": (1915, 5261, 155),
+}
+
+
+@dataclass
+class SyntheticDF:
+    N: int
+    Q: int
+    n_occ: int
+    J2c: np.ndarray            # (Q, Q) SPD metric
+    T: np.ndarray              # (Q, N, N) symmetric in the last two
+    C: np.ndarray              # (N, N) orthonormal columns ("MO coefficients")
+    H: np.ndarray              # (N, N) symmetric
+    mask: Optional[np.ndarray]  # bool (N, N) symmetric keep-mask or None
+    aux_shell_nbas: List[int]
+
+
+def aux_shells(Q: int, rng: np.random.Generator) -> List[int]:
+    """Cartesian shell sizes 1,3,6,10 summing to Q (aux sets are s..f)."""
+    out: List[int] = []
+    left = Q
+    sizes = np.array([1, 3, 6, 10])
+    while left > 0:
+        s = int(rng.choice(sizes[sizes <= left]))
+        out.append(s)
+        left -= s
+    return out
+
+
+def band_mask(N: int, kept_fraction: float, rng: np.random.Generator) -> np.ndarray:
+    """Symmetric band |p-q| <= w plus seeded raggedness so that kept/N^2 ~ kept_fraction
+    (C20H42 picture of the reference: ~0.47)."""
+    w = max(1, int(round(N * (1.0 - np.sqrt(max(0.0, 1.0 - kept_fraction))))))
+    i = np.arange(N)
+    d = np.abs(i[:, None] - i[None, :])
+    m = d <= w
+    salt = np.triu(rng.random((N, N)) < 0.02, 1)
+    near = (d > w) & (d <= w + max(2, w // 8))
+    m = m | ((salt | salt.T) & near)
+    pepper = np.triu(rng.random((N, N)) < 0.02, 1)
+    drop = (pepper | pepper.T) & (d >= max(1, w - max(2, w // 8))) & (d <= w)
+    m = m & ~drop
+    np.fill_diagonal(m, True)
+    return m
+
+
+def make(N: int, Q: int, n_occ: int, seed: int = SEED, kept_fraction: Optional[float] = None,
+         dtype=np.float64) -> SyntheticDF:
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((Q, N, N)) * 0.1
+    T = 0.5 * (A + A.transpose(0, 2, 1))
+    del A
+    M = rng.standard_normal((Q, Q))
+    J2c = M @ M.T + Q * np.eye(Q)
+    Cfull, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    Hs = rng.standard_normal((N, N))
+    H = 0.5 * (Hs + Hs.T)
+    shells = aux_shells(Q, rng)
+    mask = None
+    if kept_fraction is not None:
+        mask = band_mask(N, kept_fraction, rng)
+        T = T * mask[None, :, :]
+    return SyntheticDF(N, Q, n_occ, J2c, np.ascontiguousarray(T), Cfull, H, mask, shells)
+
+
+def make_config(name: str, **kw) -> SyntheticDF:
+    N, Q, o = CONFIGS[name]
+    return make(N, Q, o, **kw)

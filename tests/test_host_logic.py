@@ -1,0 +1,113 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol
+include/jcdf.h declares, fails loudly without a GPU, and the host logic (shard
+rule, packing map, options, host Cholesky) behaves like the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import juliachem_jl_amd as jc
+from juliachem_jl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "jcdf.h")).read()
+    return sorted(set(re.findall(r"\b(jcdf_[a-z_0-9A-Z]+)\s*\(", txt)) - {"jcdf_status"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+        assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
+    assert _lib.load().jcdf_abi_version() == 1000
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(jc.JCDFError) as e:
+        jc.JCDFHandle(0)
+    assert e.value.code == 3 and "no CPU fallback" in str(e.value)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "juliachem.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "oracle/" not in src.replace("never imports oracle/", ""), f
+
+
+def test_host_potrf_trtri_matches_lapack():
+    import scipy.linalg as sla
+    rng = np.random.default_rng(5)
+    for n in (1, 5, 64, 65, 200, 333):
+        M = rng.standard_normal((n, n))
+        A = M @ M.T + n * np.eye(n)
+        X = jc.host_potrf_trtri(np.tril(A))             # only the lower triangle is referenced
+        Li = sla.solve_triangular(sla.cholesky(A, lower=True), np.eye(n), lower=True)
+        assert np.allclose(X, Li, rtol=0, atol=1e-13 * np.abs(Li).max())
+        assert np.all(np.triu(X, 1) == 0.0)
+    with pytest.raises(jc.JCDFError):
+        jc.host_potrf_trtri(-np.eye(4))
+
+
+def test_shard_rule():
+    aux = jc.basis_from_shell_sizes([1, 3, 6, 10, 1, 3, 6])      # 30 functions, 7 shells
+    bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes([1, 3], nels=4), aux)
+    r = [jc.static_load_rank_indicies(k, 3, bs) for k in range(3)]
+    assert [(a.start, a.stop) for a, _ in r] == [(0, 2), (2, 4), (4, 7)]         # 7 // 3 = 2, rest to the last
+    assert [(b.start, b.stop) for _, b in r] == [(0, 4), (4, 20), (20, 30)]
+    assert [len(x) for x in jc.calculate_device_ranges_GPU(1, 1, bs)] == [30]
+
+
+def test_packing_map_matches_oracle_rule():
+    from oracle import df_fock as orc
+    rng = np.random.default_rng(1)
+    m = rng.random((17, 17)) < 0.4
+    m = m | m.T
+    np.fill_diagonal(m, True)
+    sd = jc.get_screening_metadata(m)
+    ref = orc.get_screening_metadata(m)
+    assert np.array_equal(sd.sparse_pq_index_map, ref.sparse_pq_index_map)
+    assert np.array_equal(sd.sparse_p_start_indices, ref.sparse_p_start_indices)
+    assert np.array_equal(sd.non_screened_p_indices_count, ref.non_screened_p_indices_count)
+    pp, qq = jc.packed_pq_lists(sd)
+    assert np.array_equal(pp, ref.pq_p) and np.array_equal(qq, ref.pq_q)
+    d = jc.setup_unscreened_screening_matricies(5)
+    assert d.sparse_pq_index_map[3, 2] == 3 + 5 * 2 and d.screened_indices_count == 25
+    with pytest.raises(ValueError):
+        jc.get_screening_metadata(np.triu(np.ones((3, 3), dtype=bool)))
+
+
+def test_scf_options_defaults_and_aliasing():
+    o = jc.create_scf_options({"scf_type": "df", "contraction_mode": "GPU", "dele": 1e-6, "rmsd": 1e-6})
+    assert o.density_fitting and o.df_energy_convergence == 1e-6 and o.df_density_convergence == 1e-6
+    assert o.df_max_iterations == 10 and o.max_iterations == 10            # Constants.jl:39
+    assert o.df_screening_sigma == 1e-5 and o.num_devices == 1 and o.df_use_adaptive
+    o2 = jc.create_scf_options({})
+    assert not o2.density_fitting and o2.df_energy_convergence == 1e-3 and o2.df_max_iterations == 0
+
+
+def test_timing_keys():
+    assert jc.JCTiming_key(jc.JCTC.W_time, 3) == "W_time-3"
+    assert jc.JCTiming_GPUkey(jc.JCTC.GPU_K_time, 2, 5) == "GPU_2_K_time-5"
+    assert jc.JCTiming_GPUkey(jc.JCTC.GPU_data_size_MB, 1) == "GPU_1_data_size_MB"
+
+
+def test_cpu_modes_are_refused():
+    sd = jc.SCFData(jc.get_default_gpu_data_hip())
+    bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes([1, 1], nels=2), jc.basis_from_shell_sizes([1, 1, 1]))
+    with pytest.raises(jc.JCDFError):
+        jc.df_rhf_fock_build(sd, None, None, bs, np.eye(2), 1, jc.SCFOptions(contraction_mode="screened"),
+                             np.eye(2), jc.create_jctiming())
