@@ -392,7 +392,8 @@ class JCDFHandle:
 
     def fock_build(self, C_occ: np.ndarray) -> Tuple[np.ndarray, jcdf_timings]:
         c = _f64(C_occ)
-        assert c.shape == (self.N, self.o), (c.shape, (self.N, self.o))
+        if self.N and c.shape != (self.N, self.o):
+            raise JCDFError(1, "C_occ has shape %s, expected (N, n_occ) = %s" % (c.shape, (self.N, self.o)))
         F = np.empty((self.N, self.N), dtype=np.float64, order="F")
         t = jcdf_timings()
         self._check(self._lib.jcdf_fock_build(self._h, c.ctypes.data, F.ctypes.data, C.byref(t)))

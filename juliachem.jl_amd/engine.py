@@ -1,0 +1,177 @@
+"""Device-resident driver around the HIP Fock build: one process per GPU,
+`torch.distributed` (backend "nccl" == RCCL over xGMI) for the one collective the
+path has — the all-reduce of the N x N partial Fock matrix that replaces
+MPI.Allreduce! (DensityFitting.jl:68-71) and the host axpy over devices
+(GPUDF.jl:267-277).  torch is plumbing here (device memory, streams, the
+collective, the replicated eigensolve); every kernel of the Fock build is in
+libjcdf_hip.so.
+
+`DeviceFockBuilder`   aux-sharded Fock build, inputs/outputs stay in HBM.
+`DeviceSCF`           the SCF loop body of scf_cycles_kernel (SCF.jl:399-573) and
+                      `iteration` (SCF.jl:1072-1125) with everything on the device:
+                      the caller of the hot path.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .df import JCDFHandle, host_potrf_trtri
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist
+    return 0, 1, None
+
+
+def shard_ranges(aux_shell_nbas: Sequence[int], n_shards: int) -> List[range]:
+    """Contiguous aux-shell shards, floor(S/n) shells each, remainder to the last
+    (DynamicLoad.jl:160-203)."""
+    pos = np.concatenate([[0], np.cumsum(np.asarray(aux_shell_nbas, dtype=np.int64))])
+    S = len(aux_shell_nbas)
+    per = S // n_shards
+    out = []
+    for r in range(n_shards):
+        b = per * r
+        e = S if r == n_shards - 1 else b + per
+        out.append(range(int(pos[b]), int(pos[e])))
+    return out
+
+
+class DeviceFockBuilder:
+    """F = H + sum_shards (2 J_s - K_s) with this rank's shard on this rank's GPU."""
+
+    def __init__(self, N: int, Q_total: int, n_occ: int, aux_shell_nbas: Sequence[int],
+                 device: Optional[int] = None, pq: Tuple[Optional[np.ndarray], Optional[np.ndarray]] = (None, None)):
+        self.rank, self.world, self.dist = _dist()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.N, self.Q_total, self.n_occ = N, Q_total, n_occ
+        self.ranges = shard_ranges(aux_shell_nbas, self.world)
+        self.rows = self.ranges[self.rank]
+        if len(self.rows) == 0:
+            raise ValueError("empty auxiliary shard on rank %d" % self.rank)
+        self.h = JCDFHandle(device)
+        self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
+        self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
+
+    # ---- setup -----------------------------------------------------------------
+    def set_metric(self, J2c: np.ndarray) -> None:
+        self.h.set_metric_inverse(host_potrf_trtri(J2c))     # potrf/trtri on the host, GPUDF.jl:890-891
+
+    def set_core_hamiltonian(self, H: np.ndarray) -> None:
+        self.h.set_core_hamiltonian(H if self.rank == 0 else None)     # GPUDF.jl:158-161
+
+    def push_three_center_device(self, s0: int, s1: int, T_dev: torch.Tensor) -> None:
+        """T_dev: device tensor holding the (s1-s0, P) column-major block."""
+        if s0 < self.rows.stop:
+            self.h.push_three_center_device(s0, s1, T_dev.data_ptr())
+
+    def exchange_three_center(self, T_own: torch.Tensor) -> None:
+        """One-time B formation across ranks (GPUDF.jl:918-997): every rank owns the
+        three-centre integrals of its own aux rows; block s is broadcast from its
+        owner over RCCL and accumulated by every rank r >= s (L^-1 lower triangular)."""
+        P = T_own.numel() // len(self.rows)
+        for s, rows in enumerate(self.ranges):
+            if self.world == 1:
+                blk = T_own
+            else:
+                blk = T_own if s == self.rank else torch.empty(len(rows) * P, dtype=torch.float64, device=self.device)
+                self.dist.broadcast(blk, s)
+            self.push_three_center_device(rows.start, rows.stop, blk)
+        torch.cuda.synchronize(self.device)
+
+    # ---- per iteration -----------------------------------------------------------
+    def build(self, C_occ_dev: torch.Tensor) -> torch.Tensor:
+        """C_occ_dev: (n_occ, N) row-major device tensor == (N, n_occ) column-major,
+        the layout of DensityFitting.jl:49.  Returns the reduced F (device)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr(), st)
+        if self.world > 1:
+            self.dist.all_reduce(self.F)                      # RCCL ncclAllReduce(N^2 fp64) over xGMI
+        return self.F
+
+    def close(self) -> None:
+        self.h.close()
+
+
+class DeviceSCF:
+    """SCF iteration with all matrices on the device (hcore guess, DIIS, damping;
+    SURVEY Appendix D).  Matrices are symmetric, so row/column-major coincide."""
+
+    def __init__(self, fb: DeviceFockBuilder, H: np.ndarray, S: np.ndarray, E_nuc: float, ndiis: int = 10):
+        self.fb = fb
+        dev = fb.device
+        self.N, self.n_occ = fb.N, fb.n_occ
+        self.H = torch.as_tensor(H, dtype=torch.float64, device=dev)
+        self.S = torch.as_tensor(S, dtype=torch.float64, device=dev)
+        s, U = torch.linalg.eigh(self.S)
+        keep = s >= 1.0e-6                                          # SCF.jl:142-162
+        self.X = (U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T
+        self.E_nuc = E_nuc
+        self.ndiis = ndiis
+        self.reset()
+
+    def reset(self) -> None:
+        self.F = self.H.clone()
+        self.D = torch.zeros_like(self.H)
+        self._diag()                                               # "iteration 0", SCF.jl:178-181
+        self.F_old = self.F.clone()
+        self.E_old, self.dE, self.B_dim, self.iter = 0.0, 1.0, 1, 1
+        self.e_hist: List[torch.Tensor] = []
+        self.F_hist: List[torch.Tensor] = []
+        self.trail: List[Tuple[int, float, float, float]] = []
+
+    def _diag(self) -> torch.Tensor:
+        """SCF.jl:1072-1125: F' = X F X, eigh, C = X U, D = 2 C_o C_o^T, E_elec."""
+        Fp = self.X @ self.F @ self.X
+        self.eps, U = torch.linalg.eigh(Fp)
+        self.C = self.X @ U
+        self.Co_t = self.C[:, :self.n_occ].T.contiguous()          # (o, N) row-major == (N, o) column-major
+        self.D = 2.0 * (self.Co_t.T @ self.Co_t)
+        return 0.5 * (torch.sum(self.D * self.F) + torch.sum(self.D * self.H))
+
+    def step(self) -> Tuple[float, float, float]:
+        """One pass of the loop body SCF.jl:399-573.  Returns (E, dE, D_rms)."""
+        F = self.fb.build(self.Co_t).clone()                       # SCF.jl:463
+        if self.ndiis > 0:                                         # SCF.jl:472-501
+            FDS = (F @ self.D) @ self.S
+            e = FDS - FDS.T
+            self.e_hist = [e] + self.e_hist[:self.ndiis - 1]
+            self.F_hist = [F.clone()] + self.F_hist[:self.ndiis - 1]
+            if self.iter > 1:
+                self.B_dim = min(self.B_dim + 1, self.ndiis)
+                n = self.B_dim
+                E = torch.stack([x.reshape(-1) for x in self.e_hist[:n]])
+                Bm = torch.full((n + 1, n + 1), -1.0, dtype=torch.float64, device=F.device)
+                Bm[:n, :n] = E @ E.T
+                Bm[n, n] = 0.0
+                rhs = torch.zeros(n + 1, dtype=torch.float64, device=F.device)
+                rhs[n] = -1.0
+                try:
+                    c = torch.linalg.solve(Bm, rhs)
+                    F = torch.einsum("i,imn->mn", c[:n], torch.stack(self.F_hist[:n]))
+                except Exception:                                  # "Faulty DIIS!" SCF.jl:493-499
+                    self.B_dim = 2
+        x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
+        F = (1.0 - x) * self.F_old + x * F
+        self.F = F
+        self.F_old = F.clone()
+        D_old = self.D
+        E_elec = self._diag()
+        D_rms = torch.linalg.norm(self.D - D_old)
+        E = float(E_elec) + self.E_nuc                              # one host sync per iteration
+        dE = E - self.E_old
+        drms = float(D_rms)
+        self.trail.append((self.iter, E, dE, drms))
+        self.dE, self.E_old = dE, E
+        self.iter += 1
+        return E, dE, drms
