@@ -81,6 +81,12 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id);
 int32_t jcdf_destroy(jcdf_handle *h);
 /* Message of the last failing call on `h` (h == NULL: last jcdf_create failure). */
 const char *jcdf_last_error(const jcdf_handle *h);
+/* Stream every later call on `h` enqueues its copies and kernels on.  use_own != 0:
+ * the handle's own non-blocking stream (the default after jcdf_create);
+ * otherwise `stream` is a hipStream_t of the handle's device, NULL meaning the HIP
+ * legacy default stream.  A host that produces device inputs on its own stream
+ * (e.g. PyTorch's current stream) sets that stream here so everything is ordered. */
+int32_t jcdf_set_stream(jcdf_handle *h, void *stream, int32_t use_own);
 /* ABI version of this header (major*1000 + minor). */
 int32_t jcdf_abi_version(void);
 
@@ -139,8 +145,8 @@ int32_t jcdf_set_core_hamiltonian(jcdf_handle *h, const double *H);
  * (DensityFitting.jl:62-75).  t may be NULL. */
 int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t);
 /* Same with device pointers on this handle's device.  Work is enqueued on
- * `stream` (a hipStream_t, NULL = the handle's own stream) and is NOT
- * synchronised on return, so the caller can chain an RCCL all-reduce of d_F. */
+ * `stream` (a hipStream_t; NULL = the handle's stream, see jcdf_set_stream) and is
+ * NOT synchronised on return, so the caller can chain an RCCL all-reduce of d_F. */
 int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_F, void *stream);
 /* Blocks until work enqueued by the previous call has finished; fills timings. */
 int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t);

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "jcdf_destroy": (C.c_int32, [_P]),
     "jcdf_last_error": (C.c_char_p, [_P]),
     "jcdf_abi_version": (C.c_int32, []),
+    "jcdf_set_stream": (C.c_int32, [_P, _P, C.c_int32]),
     "jcdf_configure": (C.c_int32, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "jcdf_set_metric": (C.c_int32, [_P, _P]),
     "jcdf_set_metric_inverse": (C.c_int32, [_P, _P]),
@@ -67,6 +68,13 @@ def load() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise JCDFError(-1, "HIP library not built: %s (run ./build.sh); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing it
+        # first makes libjcdf_hip.so (NEEDED libamdhip64.so.7) bind to that same copy instead of
+        # loading /opt/rocm's next to it (two runtimes -> "No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)

@@ -33,7 +33,8 @@ struct KernelRec {
 struct jcdf_handle {
     int device = -1;
     int num_cu = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream every library operation is enqueued on (jcdf_set_stream)
+    hipStream_t own_stream = nullptr;   // created by jcdf_create, the default for `stream`
     std::string err;
 
     // sizes
@@ -205,7 +206,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     }
     {
         KernelRec &r = rec_begin(h, k++, "k_coulomb_J", st);
-        hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)h->N, (unsigned)h->SJ), dim3(256),
+        hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)((h->N + J_ROWS - 1) / J_ROWS), (unsigned)h->SJ), dim3(256),
                            (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
                            (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV);
         r.flops = r.alg_flops = Ql * N * (N + 1.0);
@@ -353,7 +354,7 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
     h->device = device_id;
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("jcdf_create: ") + hipGetErrorString(e);
         delete h;
         return JCDF_ERR_HIP;
@@ -361,10 +362,11 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
         g_create_error = std::string("jcdf_create: device is ") + prop.gcnArchName +
                          ", this library contains gfx950 (MI355X) code objects only";
-        (void)hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(h->own_stream);
         delete h;
         return JCDF_ERR_NO_DEVICE;
     }
+    h->stream = h->own_stream;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     (void)hipEventCreate(&h->ev_begin);
     (void)hipEventCreate(&h->ev_end);
@@ -382,14 +384,23 @@ int32_t jcdf_destroy(jcdf_handle *h)
 {
     if (!h) return JCDF_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     free_all(h);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
     if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+    return JCDF_OK;
+}
+
+int32_t jcdf_set_stream(jcdf_handle *h, void *stream, int32_t use_own)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    JCDF_HIP(h, hipSetDevice(h->device));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = use_own ? h->own_stream : (hipStream_t)stream;
     return JCDF_OK;
 }
 
@@ -444,8 +455,9 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     h->S = (int)((Ktot + h->KS - 1) / h->KS);
     h->Wrows = (int64_t)h->S * h->KS;
     // J: slices over the aux index so that ~8 blocks per CU are in flight
-    int64_t SJ = std::max<int64_t>(1, (8 * (int64_t)h->num_cu + N - 1) / N);
-    SJ = std::min<int64_t>(SJ, std::max<int64_t>(1, h->Ql / 32));
+    const int64_t jrow_blocks = (N + J_ROWS - 1) / J_ROWS;
+    int64_t SJ = std::max<int64_t>(1, (8 * (int64_t)h->num_cu + jrow_blocks - 1) / jrow_blocks);
+    SJ = std::min<int64_t>(SJ, std::max<int64_t>(1, h->Ql / 16));
     h->QS = (int)((h->Ql + SJ - 1) / SJ);
     h->SJ = (int)((h->Ql + h->QS - 1) / h->QS);
     if ((size_t)h->QS * 8 > 48 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux slice too long");

@@ -343,6 +343,13 @@ class JCDFHandle:
         except Exception:
             pass
 
+    def set_stream(self, stream: Optional[int]) -> None:
+        """stream: a hipStream_t value (0 = legacy default stream); None = the handle's own stream."""
+        if stream is None:
+            self._check(self._lib.jcdf_set_stream(self._h, None, 1))
+        else:
+            self._check(self._lib.jcdf_set_stream(self._h, stream or None, 0))
+
     def configure(self, N: int, Q_total: int, q0: int, q1: int, n_occ: int,
                   pq_p: Optional[np.ndarray] = None, pq_q: Optional[np.ndarray] = None) -> None:
         if pq_p is None:

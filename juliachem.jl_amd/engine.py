@@ -60,6 +60,9 @@ class DeviceFockBuilder:
         if len(self.rows) == 0:
             raise ValueError("empty auxiliary shard on rank %d" % self.rank)
         self.h = JCDFHandle(device)
+        # every library operation goes on torch's current stream: ordered with the torch ops
+        # that produce its inputs (C_occ, the T blocks) and consume its output (F)
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
         self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
 
@@ -93,8 +96,7 @@ class DeviceFockBuilder:
     def build(self, C_occ_dev: torch.Tensor) -> torch.Tensor:
         """C_occ_dev: (n_occ, N) row-major device tensor == (N, n_occ) column-major,
         the layout of DensityFitting.jl:49.  Returns the reduced F (device)."""
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr(), st)
+        self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr())
         if self.world > 1:
             self.dist.all_reduce(self.F)                      # RCCL ncclAllReduce(N^2 fp64) over xGMI
         return self.F
