@@ -48,7 +48,7 @@ struct jcdf_handle {
     bool dense_map = true;
 
     // device buffers
-    double *dB = nullptr, *dCpad = nullptr, *dW = nullptr, *dVpart = nullptr, *dV = nullptr;
+    double *dB = nullptr, *dCpad = nullptr, *dCperm = nullptr, *dW = nullptr, *dVpart = nullptr, *dV = nullptr;
     double *dJpart = nullptr, *dKslab = nullptr, *dH = nullptr, *dF = nullptr, *dC = nullptr;
     double *dLinvT = nullptr;
     int64_t ldl = 0, linv_rows = 0;
@@ -109,7 +109,7 @@ void dev_free(jcdf_handle *h, T **p, int64_t count)
 void free_all(jcdf_handle *h)
 {
     (void)hipSetDevice(h->device);
-    double **bufs[] = {&h->dB, &h->dCpad, &h->dW, &h->dVpart, &h->dV, &h->dJpart, &h->dKslab,
+    double **bufs[] = {&h->dB, &h->dCpad, &h->dCperm, &h->dW, &h->dVpart, &h->dV, &h->dJpart, &h->dKslab,
                        &h->dH, &h->dF, &h->dC, &h->dLinvT, &h->dRaw, &h->dTint};
     for (auto b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
@@ -129,7 +129,7 @@ void launch_W_t(jcdf_handle *h, hipStream_t st)
     const int64_t outer = h->Ql * h->n_ntiles;
     const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
     hipLaunchKernelGGL(k_exchange_W<WM>, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
-                       h->dCpad, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
+                       h->dCpad, h->dCperm, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
                        h->opad, h->n_mtiles, h->n_ntiles);
 }
 
@@ -192,7 +192,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_prep_C", st);
         const int64_t tot = h->Np * h->opad;
         hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
-                           (int)h->o, (int)h->Np, h->opad, h->dCpad);
+                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->dCpad, h->dCperm);
         r.alg_bytes = 8.0 * N * o;
         (void)hipEventRecord(r.e1, st);
     }
@@ -448,9 +448,15 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     const int nT = h->n_ntiles;
     h->ntri = nT * (nT + 1) / 2;
     const int64_t Ktot = h->Ql * h->o;
-    const int64_t max_chunks = std::max<int64_t>(1, Ktot / (8 * KC));      // >= 8 LDS stages per slice
-    int64_t S = std::max<int64_t>(1, (2 * (int64_t)h->num_cu) / h->ntri);
-    S = std::min(S, max_chunks);
+    // Split-K: all tiles of one k-slice run on one XCD (they share W rows through that L2), so
+    // the slice count is a multiple of 8 and sized so that ntri * S/8 workgroups fill, but do
+    // not exceed, one XCD's residency (2 workgroups per CU): every workgroup is resident in a
+    // single round and all finish together.
+    const int64_t max_chunks = std::max<int64_t>(1, Ktot / (4 * KC));      // >= 4 LDS stages per slice
+    const int64_t slots_per_xcd = 2 * std::max(1, h->num_cu / 8);
+    int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ntri);
+    int64_t S = 8 * per_xcd;
+    if (S > max_chunks) S = std::max<int64_t>(1, max_chunks);
     h->KS = (int)roundup((Ktot + S - 1) / S, KC);
     h->S = (int)((Ktot + h->KS - 1) / h->KS);
     h->Wrows = (int64_t)h->S * h->KS;
@@ -465,6 +471,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     int32_t rc;
     if ((rc = dev_alloc(h, &h->dB, h->Ql * h->Nk * h->Np, true))) return rc;
     if ((rc = dev_alloc(h, &h->dCpad, h->Np * h->opad, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dCperm, h->Np * h->opad, true))) return rc;
     if ((rc = dev_alloc(h, &h->dW, h->Wrows * h->Np, true))) return rc;
     if ((rc = dev_alloc(h, &h->dVpart, h->Ql * h->nvp, true))) return rc;
     if ((rc = dev_alloc(h, &h->dV, h->Ql, true))) return rc;

@@ -48,7 +48,10 @@ struct GemmCfg {
 // nchunks = K / KC.  All tile loads must be in bounds (buffers are padded).
 // STREAM_B: the B operand is read exactly once from HBM by the whole grid (the
 // 3-index tensor) -> non-temporal loads keep it from evicting the reused operand.
-template <class Cfg, bool STREAM_B>
+// ABL: timing-only ablation bits for tools/w_ablate.hip (0 in the product):
+//   1 = no A global loads after the first stage, 2 = no B global loads after the first
+//   stage, 4 = no LDS re-staging (ds_write) after the first stage, 8 = no barrier in the loop.
+template <class Cfg, bool STREAM_B, int ABL = 0>
 __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int64_t lda,
                                              const double *__restrict__ Bg, int64_t ldb,
                                              int nchunks, double4_t (&acc)[Cfg::WM][Cfg::WN],
@@ -72,6 +75,7 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
     auto load_stage = [&](int chunk) {
         const double *Ap = Ag + (int64_t)chunk * KC * lda;
         const double *Bp = Bg + (int64_t)chunk * KC * ldb;
+        if (!((ABL & 1) && chunk > 0))
 #pragma unroll
         for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {
             const int idx = tid + i * NT;
@@ -80,6 +84,7 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
                 ra[i] = *reinterpret_cast<const double2_t *>(Ap + (int64_t)r * lda + 2 * c);
             }
         }
+        if (!((ABL & 2) && chunk > 0))
 #pragma unroll
         for (int i = 0; i < Cfg::B_PER_THREAD; ++i) {
             const int idx = tid + i * NT;
@@ -136,9 +141,9 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
         }
 
-        if (more) store_stage(cur ^ 1);       // other buffer: last read before the previous barrier
-        __syncthreads();
-        cur ^= 1;
+        if (more && !(ABL & 4)) store_stage(cur ^ 1);   // other buffer: last read before the previous barrier
+        if (!(ABL & 8)) __syncthreads();
+        if (!(ABL & 4)) cur ^= 1;
     }
 }
 

@@ -22,13 +22,26 @@ constexpr int TILE_P = 128;     // p-tile of every MFMA kernel == padding unit o
 // Replaces the per-p gather buffer of build_non_zero_coefficients_kernel
 // (GPUDF.jl:459-480): the W kernel reads C rows from LDS directly.
 // ---------------------------------------------------------------------------
-__global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int opad,
-                         double *__restrict__ Cpad)
+// Also writes Cperm: the same numbers pre-permuted into the fp64 MFMA accumulator
+// layout of the W kernel's output tiles, so that its fused-V epilogue reads
+// C[p][i] with fully coalesced 16-B loads:
+//   Cperm[mt][ct][t][lane][e] = C[p = 16 ct + (lane&15)][i = mt*TMw + 16 (t/2) + (lane>>4) + 4 (2 (t&1) + e)]
+// (ct = 16-column tile, t < 2*WMw, e < 2), i.e. element e of lane's t-th double2
+// pairs with accumulator acc[m = t/2][.][j = 2 (t&1) + e].
+__global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int opad, int WMw,
+                         double *__restrict__ Cpad, double *__restrict__ Cperm)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Np * opad) return;
     const int q = (int)(idx / opad), i = (int)(idx % opad);
-    Cpad[idx] = (q < N && i < o) ? C[q + (int64_t)N * i] : 0.0;
+    const double v = (q < N && i < o) ? C[q + (int64_t)N * i] : 0.0;
+    Cpad[idx] = v;
+    const int TMw = 16 * WMw;
+    const int mt = i / TMw, il = i % TMw;
+    const int m = il >> 4, lk = il & 3, j = (il & 15) >> 2;
+    const int t = 2 * m + (j >> 1), e = j & 1;
+    const int ct = q >> 4, lane = (q & 15) | (lk << 4);
+    Cperm[((((int64_t)mt * (Np / 16) + ct) * (2 * WMw) + t) * 64 + lane) * 2 + e] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -37,16 +50,25 @@ __global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int
 // Reference: calculate_W_screened_GPU (GPUDF.jl:637-667; N small GEMMs) /
 // DenseGPUDF.jl:107 (W) and GPUDF.jl:539-542 / DenseGPUDF.jl:99 (V gemv, which
 // costs the reference one extra pass over B).
-// Workgroup = 8 waves side by side along p (TN = 128), all WM*16 orbitals.
+//
+// Workgroup = 4 waves (one per SIMD) side by side along p, each WM x 2 MFMA tiles:
+// TN = 128 columns, all WM*16 orbitals of one aux index Q.  Two such workgroups
+// are co-resident per CU, so the two waves sharing a SIMD's matrix pipe belong to
+// different workgroups and do not hit their barriers together.
+// Variants measured in one process on the C20H42 shape (tools/w_ablate.hip,
+// profiles/r01_w_ablate.txt): this one 61 TF executed; 8 waves x (WM x 1) 59 TF;
+// 8 waves, 256 columns 54 TF; B fragments loaded straight from HBM into registers
+// (no LDS for B, barrier every 32 rows) 55-56 TF; MFMA + ds_read only (no loads,
+// no barrier) 70 TF = the ceiling of this loop at the clock the chip holds.
 // ---------------------------------------------------------------------------
 template <int WM>
-using WCfg = GemmCfg<WM, 1, 1, 8, KC>;
+using WCfg = GemmCfg<WM, 2, 1, 4, KC>;
 
-template <int WM>
-__global__ __launch_bounds__(512) void k_exchange_W(
-    const double *__restrict__ B, const double *__restrict__ Cpad, double *__restrict__ W,
-    double *__restrict__ vpart, int Ql, int o, int Nk, int Np, int opad, int n_mtiles,
-    int n_ntiles)
+template <int WM, bool FUSE_V = true>
+__global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
+    const double *__restrict__ B, const double *__restrict__ Cpad, const double *__restrict__ Cperm,
+    double *__restrict__ W, double *__restrict__ vpart, int Ql, int o, int Nk, int Np, int opad,
+    int n_mtiles, int n_ntiles)
 {
     using Cfg = WCfg<WM>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -61,38 +83,43 @@ __global__ __launch_bounds__(512) void k_exchange_W(
     const int Q = (int)(outer / n_ntiles);
     const int nt = (int)(outer % n_ntiles);
 
-    double4_t acc[WM][1];
+    double4_t acc[WM][2];
 #pragma unroll
-    for (int m = 0; m < WM; ++m) acc[m][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < WM; ++m) acc[m][0] = acc[m][1] = double4_t{0.0, 0.0, 0.0, 0.0};
 
     const double *Ag = Cpad + mt * Cfg::TM;
     const double *Bg = B + (int64_t)Q * Nk * Np + nt * Cfg::TN;
     gemm_tn_core<Cfg, true>(Ag, opad, Bg, Np, Nk / KC, acc, smem);
 
-    const int p = nt * Cfg::TN + tile_col<Cfg>(0);
-    const double *Cp = Cpad + (int64_t)p * opad;
     double vsum = 0.0;
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+    for (int n = 0; n < 2; ++n) {
+        const int p = nt * Cfg::TN + tile_col<Cfg>(n);
+        if (FUSE_V) {   // C[p][i] in accumulator layout: 2*WM coalesced 16-B loads (zero where i >= o)
+            const double2_t *cp = reinterpret_cast<const double2_t *>(Cperm) +
+                                  ((int64_t)mt * (Np / 16) + (p >> 4)) * (2 * WM) * 64 + (threadIdx.x & 63);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = mt * Cfg::TM + tile_row<Cfg>(m, j);
-            const double w = acc[m][0][j];
-            if (i < o) W[((int64_t)Q * o + i) * Np + p] = w;
-            vsum += w * Cp[i];                            // Cpad is 0 for i >= o
+            for (int t = 0; t < 2 * WM; ++t) {
+                const double2_t c = cp[t * 64];
+                vsum += acc[t >> 1][n][2 * (t & 1)] * c.x + acc[t >> 1][n][2 * (t & 1) + 1] * c.y;
+            }
         }
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = mt * Cfg::TM + tile_row<Cfg>(m, j);
+                if (i < o) W[((int64_t)Q * o + i) * Np + p] = acc[m][n][j];
+            }
+    }
+    if (!FUSE_V) return;
     // deterministic workgroup reduction: butterfly inside the wave, fixed order across waves
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
-    __syncthreads();                                       // gemm core is done with smem
-    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = vsum;
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = vsum;   // all waves passed the core's last barrier
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += smem[w];
-        vpart[(int64_t)Q * (n_ntiles * n_mtiles) + nt * n_mtiles + mt] = s;
-    }
+    if (threadIdx.x == 0)
+        vpart[(int64_t)Q * (n_ntiles * n_mtiles) + nt * n_mtiles + mt] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
 }
 
 // ---------------------------------------------------------------------------
