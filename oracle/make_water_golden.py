@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Extracts the golden DATA of the reference's own run log
+/root/reference/water_ccpvdz_out.log into tests/golden/water_ccpvdz_rifit.json:
+basis + auxiliary basis exponents/coefficients as printed (:44-157), the
+COM-shifted geometry in bohr (:196-198), SCF settings (:205-216), the printed
+iteration trail (iter, E, dE, Drms; :253-523) and the final energy (:563).
+Numbers only — no reference source text is copied.  Run in the build container
+(the reference is not present on the GPU box)."""
+import json
+import os
+import re
+import sys
+
+LOG = "/root/reference/water_ccpvdz_out.log"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "water_ccpvdz_rifit.json")
+AM = {"S": 0, "P": 1, "D": 2, "F": 3, "G": 4}
+
+
+def parse_basis(lines):
+    atoms, cur_atom, cur_shell, last_id = [], None, None, None
+    for ln in lines:
+        m = re.match(r"Atom #(\d+) \((\w+)\):", ln)
+        if m:
+            cur_atom = {"symbol": m.group(2), "shells": []}
+            atoms.append(cur_atom)
+            last_id = None
+            continue
+        m = re.match(r"\s+(\d+)\s+([SPDFG])\s+(\d+)\s+([-\d.]+)\s+([-\d.]+)\s*$", ln)
+        if m and cur_atom is not None:
+            sid = int(m.group(1))
+            if sid != last_id:
+                cur_shell = {"l": AM[m.group(2)], "exps": [], "coefs": []}
+                cur_atom["shells"].append(cur_shell)
+                last_id = sid
+            cur_shell["exps"].append(float(m.group(4)))
+            cur_shell["coefs"].append(float(m.group(5)))
+    return atoms
+
+
+def main():
+    txt = open(LOG).read().splitlines()
+    i_aux = next(i for i, l in enumerate(txt) if "Printing Auxillary basis set" in l)
+    i_meta = next(i for i, l in enumerate(txt) if "Printing basis set metadata" in l)
+    i_bas = next(i for i, l in enumerate(txt) if "Printing basis set..." in l)
+    prim = parse_basis(txt[i_bas:i_aux])
+    aux = parse_basis(txt[i_aux:i_meta])
+    i_xyz = next(i for i, l in enumerate(txt) if "in xyz format" in l)
+    geom = []
+    for l in txt[i_xyz:i_xyz + 12]:
+        m = re.match(r"^([A-Z][a-z]?)\s+([-\d.eE]+)\s+([-\d.eE]+)\s+([-\d.eE]+)\s*$", l)
+        if m:
+            geom.append({"symbol": m.group(1), "center": [float(m.group(k)) for k in (2, 3, 4)]})
+    trail = []
+    for l in txt:
+        m = re.match(r"^(\d+)\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(\d+\.\d{10})\s*$", l)
+        if m:
+            trail.append([int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))])
+    e_final = float(next(re.search(r"Total SCF Energy: (-?[\d.]+) h", l).group(1) for l in txt if "Total SCF Energy" in l))
+    meta = {}
+    for l in txt:
+        for key in ("Number of basis functions", "Number of auxillary basis functions", "Number of electrons",
+                    "Energy Convergence", "Density Convergence", "DF Max Iterations", "Contraction Mode", "Guess"):
+            m = re.match(r"^%s: (.+)$" % re.escape(key), l.strip())
+            if m and key not in meta:
+                meta[key] = m.group(1)
+    out = {"source": "water_ccpvdz_out.log (JuliaChem.jl reference run; lines 44-157, 196-198, 205-216, 253-523, 563)",
+           "units": "bohr (COM-shifted, as printed)", "atoms": geom,
+           "basis": {a["symbol"]: a["shells"] for a in prim}, "aux_basis": {a["symbol"]: a["shells"] for a in aux},
+           "atom_order": [a["symbol"] for a in prim], "charges": {"O": 8, "H": 1},
+           "settings": meta, "trail": trail, "final_energy": e_final}
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    json.dump(out, open(OUT, "w"), indent=1)
+    print("wrote", os.path.normpath(OUT), len(trail), "iterations, E =", e_final,
+          "| shells", [len(a["shells"]) for a in prim], [len(a["shells"]) for a in aux])
+
+
+if __name__ == "__main__":
+    sys.exit(main())
