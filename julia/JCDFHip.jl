@@ -1,0 +1,167 @@
+# JCDFHip.jl — thin ccall glue between JuliaChem.jl and libjcdf_hip.so (include/jcdf.h).
+#
+# NOT runnable in the build image (no Julia there); it is the reference-side binding a
+# JuliaChem maintainer adds (see INTEGRATION.md).  Pure ccall, no CUDA.jl / AMDGPU.jl.
+# It provides the two things the reference's informal "GPU operator API" consists of
+# (SURVEY.md 8b): an SCFGPUData subtype and a function with the signature of
+# df_rhf_fock_build_GPU! (src/rhf/energy/DensityFitting/GPUDF.jl:11-14).
+#
+# Wiring (3 edits in JuliaChem):
+#   src/shared/Shared.jl          include("GPUData_hip.jl")     -> the struct below
+#   src/rhf/energy/SCF.jl:389-393 contraction_mode == "HIP"  ->  gpu_data = SCFGPUData_hip()
+#   src/rhf/energy/DensityFitting/DensityFitting.jl:51
+#       if scf_options.contraction_mode == "HIP"
+#           df_rhf_fock_build_HIP!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
+#                                  occupied_orbital_coefficients, iteration, scf_options, H, jc_timing)
+# With `"contraction_mode": "HIP"` in keywords.scf, example_scripts/minimal-rhf.jl runs unchanged.
+
+module JCDFHip
+
+using JuliaChem.Shared
+using JuliaChem.Shared.JCTC
+using LinearAlgebra
+using MPI
+
+const libjcdf = get(ENV, "JCDF_HIP_LIB", "libjcdf_hip.so")
+
+# ---- status handling: non-zero status -> error(), the reference's convention (GPUDF.jl:39-41)
+struct JCDFTimings                      # mirrors jcdf_timings (include/jcdf.h), seconds
+    non_zero_coeff_time::Cdouble
+    W_time::Cdouble
+    K_time::Cdouble
+    V_time::Cdouble
+    J_time::Cdouble
+    density_time::Cdouble
+    H_add_time::Cdouble
+    copy_J_time::Cdouble
+    fock_time::Cdouble
+    copy_time::Cdouble
+end
+
+function check(h::Ptr{Cvoid}, rc::Int32)
+    if rc != 0
+        msg = unsafe_string(ccall((:jcdf_last_error, libjcdf), Cstring, (Ptr{Cvoid},), h))
+        error("libjcdf_hip status $rc: $msg")
+    end
+end
+
+# ---- the SCFGPUData subtype (counterpart of SCFGPUData_cuda, shared/GPUData_cuda.jl:4-38)
+mutable struct SCFGPUData_hip <: SCFGPUData
+    handles::Vector{Ptr{Cvoid}}                 # one per device of this rank
+    device_Q_range_lengths::Vector{Int}
+    device_Q_indices::Vector{UnitRange{Int}}
+    number_of_devices_used::Int
+    host_fock::Vector{Matrix{Float64}}
+    SCFGPUData_hip() = new(Ptr{Cvoid}[], Int[], UnitRange{Int}[], 0, Matrix{Float64}[])
+end
+
+function destroy!(gd::SCFGPUData_hip)
+    for h in gd.handles
+        ccall((:jcdf_destroy, libjcdf), Int32, (Ptr{Cvoid},), h)
+    end
+    empty!(gd.handles)
+end
+
+# ---- setup: iteration == 1 branch of df_rhf_fock_build_GPU! (GPUDF.jl:37-165)
+function setup!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets, scf_options, H, jc_timing)
+    comm = MPI.COMM_WORLD
+    rank = MPI.Comm_rank(comm); n_ranks = MPI.Comm_size(comm)
+    num_devices = scf_options.num_devices
+    gd = scf_data.gpu_data::SCFGPUData_hip
+    N = scf_data.μ; A = scf_data.A; occ = scf_data.occ
+
+    # host integrals + screening exactly as the reference does them (they stay on the host)
+    two_center_integrals = calculate_two_center_intgrals(jeri_engine_thread_df, basis_sets, scf_options)   # GPUDF.jl:43
+    get_screening_metadata!(scf_data, scf_options.df_screening_sigma, jeri_engine_thread,
+                            two_center_integrals, basis_sets, jc_timing)                                    # GPUDF.jl:45
+    sd = scf_data.screening_data
+    P = sd.screened_indices_count
+    # inverse of sparse_pq_index_map (1-based Julia -> 0-based C), what GPUDF.jl:422-438 builds on the device
+    pq_p = Vector{Int64}(undef, P); pq_q = Vector{Int64}(undef, P)
+    for pp in 1:N, qq in 1:N
+        idx = sd.sparse_pq_index_map[qq, pp]
+        if idx != 0
+            pq_p[idx] = pp - 1; pq_q[idx] = qq - 1
+        end
+    end
+    # L^-1 on the host, GPUDF.jl:890-891
+    LinearAlgebra.LAPACK.potrf!('L', two_center_integrals)
+    LinearAlgebra.LAPACK.trtri!('L', 'N', two_center_integrals)
+
+    device_Q_indices, _, device_Q_range_lengths, _ =
+        calculate_device_ranges_GPU(scf_data, num_devices, n_ranks, basis_sets)                             # GPUDF.jl:1026-1056
+    gd.device_Q_indices = device_Q_indices; gd.device_Q_range_lengths = device_Q_range_lengths
+    gd.number_of_devices_used = num_devices
+    for dev in 1:num_devices
+        g = dev + rank * num_devices
+        rows = device_Q_indices[g]
+        href = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:jcdf_create, libjcdf), Int32, (Ref{Ptr{Cvoid}}, Int32), href, dev - 1)
+        rc == 0 || error(unsafe_string(ccall((:jcdf_last_error, libjcdf), Cstring, (Ptr{Cvoid},), C_NULL)))
+        h = href[]
+        check(h, ccall((:jcdf_configure, libjcdf), Int32,
+                       (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
+                       h, N, A, first(rows) - 1, last(rows), occ, P, pq_p, pq_q))
+        check(h, ccall((:jcdf_set_metric_inverse, libjcdf), Int32, (Ptr{Cvoid}, Ptr{Float64}), h, two_center_integrals))
+        check(h, ccall((:jcdf_set_core_hamiltonian, libjcdf), Int32, (Ptr{Cvoid}, Ptr{Float64}),
+                       h, (rank == 0 && dev == 1) ? H : C_NULL))                                            # GPUDF.jl:158-161
+        push!(gd.handles, h)
+        push!(gd.host_fock, zeros(Float64, N, N))
+    end
+    # three-centre blocks: block g is computed by its owner (GPUDF.jl:51-57), broadcast, and pushed
+    # to every local handle; the library skips blocks above the diagonal of L^-1.
+    for g in 1:(num_devices * n_ranks)
+        owner = (g - 1) ÷ num_devices
+        rows = device_Q_indices[g]
+        T = owner == rank ?
+            calculate_three_center_integrals(jeri_engine_thread_df, basis_sets, scf_options, scf_data, g - 1,
+                                             num_devices * n_ranks, true) :
+            zeros(Float64, length(rows), P)
+        n_ranks > 1 && MPI.Bcast!(T, owner, comm)
+        for h in gd.handles
+            check(h, ccall((:jcdf_push_three_center, libjcdf), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}),
+                           h, first(rows) - 1, last(rows), T))
+        end
+    end
+    jc_timing.non_timing_data[JCTC.contraction_algorithm] = "screened hip"
+    jc_timing.non_timing_data[JCTC.GPU_num_devices] = string(num_devices)
+end
+
+# ---- the operator: same signature and side effects as df_rhf_fock_build_GPU! (GPUDF.jl:11-14)
+function df_rhf_fock_build_HIP!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
+                                occupied_orbital_coefficients::Matrix{Float64}, iteration::Int,
+                                scf_options, H::Matrix{Float64}, jc_timing)
+    gd = scf_data.gpu_data::SCFGPUData_hip
+    iteration == 1 && setup!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets, scf_options, H, jc_timing)
+    times = Vector{JCDFTimings}(undef, length(gd.handles))
+    total = @elapsed begin
+        Threads.@sync for (dev, h) in enumerate(gd.handles)          # one task per device, GPUDF.jl:189-193
+            Threads.@spawn begin
+                t = Ref{JCDFTimings}()
+                check(h, ccall((:jcdf_fock_build, libjcdf), Int32,
+                               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{JCDFTimings}),
+                               h, occupied_orbital_coefficients, gd.host_fock[dev], t))   # C_occ is (N, occ) column-major
+                times[dev] = t[]
+            end
+        end
+    end
+    scf_data.two_electron_fock = gd.host_fock[1]                      # host reduce over devices, GPUDF.jl:267-277
+    for dev in 2:length(gd.handles)
+        axpy!(1.0, gd.host_fock[dev], scf_data.two_electron_fock)
+    end
+    for (dev, t) in enumerate(times)                                   # timing keys, GPUDF.jl:280-301
+        jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_W_time, dev, iteration)] = t.W_time
+        jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_K_time, dev, iteration)] = t.K_time
+        jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_V_time, dev, iteration)] = t.V_time
+        jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_J_time, dev, iteration)] = t.J_time
+        jc_timing.timings[JCTiming_GPUkey(JCTC.gpu_fock_time, dev, iteration)] = t.fock_time
+        jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_non_zero_coeff_time, dev, iteration)] = t.non_zero_coeff_time
+    end
+    jc_timing.timings[JCTiming_key(JCTC.fock_time, iteration)] = maximum(t.fock_time for t in times)
+    jc_timing.timings[JCTiming_key(JCTC.total_fock_gpu_time, iteration)] = total
+    return nothing       # ranks are summed by the caller's MPI.Allreduce! (DensityFitting.jl:68-71)
+end
+
+export SCFGPUData_hip, df_rhf_fock_build_HIP!, destroy!
+
+end # module

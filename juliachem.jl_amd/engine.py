@@ -44,6 +44,31 @@ def shard_ranges(aux_shell_nbas: Sequence[int], n_shards: int) -> List[range]:
     return out
 
 
+def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int, dist, T_own, alloc, push) -> None:
+    """One-time B formation across ranks (reference: GPUDF.jl:918-997, host-staged
+    MPI.Send/Recv!).  Every rank owns the three-centre integrals of its own aux rows;
+    block s is broadcast from its owner and offered to `push(s0, s1, block)`; a rank r
+    only accumulates blocks with rows_s <= rows_r (L^-1 is lower triangular), which
+    `push` decides.  `alloc(n)` returns an empty receive buffer of n doubles.
+    Backend-agnostic (RCCL on device tensors, gloo on CPU tensors in the tests)."""
+    P = T_own.numel() // len(ranges[rank])
+    for s, rows in enumerate(ranges):
+        if world == 1:
+            blk = T_own
+        else:
+            blk = T_own if s == rank else alloc(len(rows) * P)
+            dist.broadcast(blk, s)
+        push(rows.start, rows.stop, blk)
+
+
+def allreduce_fock(F, world: int, dist):
+    """Sum of the per-shard partial Fock matrices: MPI.Allreduce!(two_electron_fock)
+    of DensityFitting.jl:68-71 as ONE collective on the N x N buffer."""
+    if world > 1:
+        dist.all_reduce(F)
+    return F
+
+
 class DeviceFockBuilder:
     """F = H + sum_shards (2 J_s - K_s) with this rank's shard on this rank's GPU."""
 
@@ -82,14 +107,9 @@ class DeviceFockBuilder:
         """One-time B formation across ranks (GPUDF.jl:918-997): every rank owns the
         three-centre integrals of its own aux rows; block s is broadcast from its
         owner over RCCL and accumulated by every rank r >= s (L^-1 lower triangular)."""
-        P = T_own.numel() // len(self.rows)
-        for s, rows in enumerate(self.ranges):
-            if self.world == 1:
-                blk = T_own
-            else:
-                blk = T_own if s == self.rank else torch.empty(len(rows) * P, dtype=torch.float64, device=self.device)
-                self.dist.broadcast(blk, s)
-            self.push_three_center_device(rows.start, rows.stop, blk)
+        exchange_three_center_blocks(
+            self.ranges, self.rank, self.world, self.dist, T_own,
+            lambda n: torch.empty(n, dtype=torch.float64, device=self.device), self.push_three_center_device)
         torch.cuda.synchronize(self.device)
 
     # ---- per iteration -----------------------------------------------------------
@@ -97,9 +117,7 @@ class DeviceFockBuilder:
         """C_occ_dev: (n_occ, N) row-major device tensor == (N, n_occ) column-major,
         the layout of DensityFitting.jl:49.  Returns the reduced F (device)."""
         self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr())
-        if self.world > 1:
-            self.dist.all_reduce(self.F)                      # RCCL ncclAllReduce(N^2 fp64) over xGMI
-        return self.F
+        return allreduce_fock(self.F, self.world, self.dist)   # RCCL ncclAllReduce(N^2 fp64) over xGMI
 
     def close(self) -> None:
         self.h.close()
