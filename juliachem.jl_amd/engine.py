@@ -146,8 +146,13 @@ class DeviceSCF:
         self._diag()                                               # "iteration 0", SCF.jl:178-181
         self.F_old = self.F.clone()
         self.E_old, self.dE, self.B_dim, self.iter = 0.0, 1.0, 1, 1
-        self.e_hist: List[torch.Tensor] = []
-        self.F_hist: List[torch.Tensor] = []
+        # DIIS history: ring buffers on the device (slot of the newest entry = head); the small
+        # Pulay matrix lives on the host and gets ONE new row of dot products per iteration
+        nd = max(self.ndiis, 1)
+        self.e_hist = torch.zeros((nd, self.N * self.N), dtype=torch.float64, device=self.H.device)
+        self.F_hist = torch.zeros((nd, self.N * self.N), dtype=torch.float64, device=self.H.device)
+        self.head, self.n_hist = -1, 0
+        self.Bmat = np.zeros((nd, nd))
         self.trail: List[Tuple[int, float, float, float]] = []
 
     def _diag(self) -> torch.Tensor:
@@ -159,39 +164,71 @@ class DeviceSCF:
         self.D = 2.0 * (self.Co_t.T @ self.Co_t)
         return 0.5 * (torch.sum(self.D * self.F) + torch.sum(self.D * self.H))
 
+    profile = False
+
+    def _mark(self, name: str) -> None:
+        """diagnostic: wall time (device drained) since the previous mark, per segment"""
+        if self.profile:
+            import time
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.seg.setdefault(name, []).append((now - self._t) * 1e3)
+            self._t = now
+
     def step(self) -> Tuple[float, float, float]:
         """One pass of the loop body SCF.jl:399-573.  Returns (E, dE, D_rms)."""
+        if self.profile:
+            import time
+            torch.cuda.synchronize()
+            self._t = time.perf_counter()
+            if not hasattr(self, "seg"):
+                self.seg = {}
         F = self.fb.build(self.Co_t).clone()                       # SCF.jl:463
+        self._mark("fock")
         if self.ndiis > 0:                                         # SCF.jl:472-501
+            nd = self.ndiis
             FDS = (F @ self.D) @ self.S
-            e = FDS - FDS.T
-            self.e_hist = [e] + self.e_hist[:self.ndiis - 1]
-            self.F_hist = [F.clone()] + self.F_hist[:self.ndiis - 1]
+            e = (FDS - FDS.T).reshape(-1)
+            self.head = (self.head + 1) % nd
+            self.n_hist = min(self.n_hist + 1, nd)
+            self.e_hist[self.head].copy_(e)
+            self.F_hist[self.head].copy_(F.reshape(-1))
+            dots = (self.e_hist @ e).cpu().numpy()                 # <e_slot, e_new> for every slot: one GEMV + one 80-B D2H
+            self.Bmat[self.head, :] = dots
+            self.Bmat[:, self.head] = dots
             if self.iter > 1:
-                self.B_dim = min(self.B_dim + 1, self.ndiis)
+                self.B_dim = min(self.B_dim + 1, nd)
                 n = self.B_dim
-                E = torch.stack([x.reshape(-1) for x in self.e_hist[:n]])
-                Bm = torch.full((n + 1, n + 1), -1.0, dtype=torch.float64, device=F.device)
-                Bm[:n, :n] = E @ E.T
+                order = [(self.head - k) % nd for k in range(n)]   # newest first, like the reference's vcat
+                Bm = -np.ones((n + 1, n + 1))
+                Bm[:n, :n] = self.Bmat[np.ix_(order, order)]
                 Bm[n, n] = 0.0
-                rhs = torch.zeros(n + 1, dtype=torch.float64, device=F.device)
+                rhs = np.zeros(n + 1)
                 rhs[n] = -1.0
                 try:
-                    c = torch.linalg.solve(Bm, rhs)
-                    F = torch.einsum("i,imn->mn", c[:n], torch.stack(self.F_hist[:n]))
-                except Exception:                                  # "Faulty DIIS!" SCF.jl:493-499
+                    c = np.linalg.solve(Bm, rhs)[:n]
+                    if not np.all(np.isfinite(c)):
+                        raise np.linalg.LinAlgError("non-finite DIIS coefficients")
+                    cfull = np.zeros(nd)
+                    cfull[order] = c
+                    F = (torch.as_tensor(cfull, device=F.device) @ self.F_hist).reshape(self.N, self.N)
+                except np.linalg.LinAlgError:                      # "Faulty DIIS!" SCF.jl:493-499
                     self.B_dim = 2
+        self._mark("diis")
         x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
         F = (1.0 - x) * self.F_old + x * F
         self.F = F
         self.F_old = F.clone()
         D_old = self.D
+        self._mark("damp")
         E_elec = self._diag()
+        self._mark("diag")
         D_rms = torch.linalg.norm(self.D - D_old)
-        E = float(E_elec) + self.E_nuc                              # one host sync per iteration
+        e_h, drms = torch.stack([E_elec, D_rms]).cpu().tolist()    # one 16-B D2H (host sync) per iteration
+        E = e_h + self.E_nuc
         dE = E - self.E_old
-        drms = float(D_rms)
         self.trail.append((self.iter, E, dE, drms))
         self.dE, self.E_old = dE, E
         self.iter += 1
+        self._mark("energy")
         return E, dE, drms
