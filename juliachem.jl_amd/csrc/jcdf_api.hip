@@ -40,7 +40,7 @@ struct jcdf_handle {
     // sizes
     int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
     int64_t Nk = 0, Np = 0;
-    int WMw = 0, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0;
+    int WMw = 0, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0, rv = 0;
     int ntri = 0, S = 0, KS = 0;
     int SJ = 0, QS = 0;
     int64_t Wrows = 0;
@@ -121,11 +121,16 @@ void free_all(jcdf_handle *h)
     h->configured = h->have_metric = h->have_B = h->have_H = h->pushed_any = false;
 }
 
-// ---- W kernel dispatch over the number of 16-orbital MFMA row tiles ---------
+// ---- W kernel dispatch over the number of 16-orbital MFMA row tiles -------------
 template <int WM>
-void launch_W_t(jcdf_handle *h, hipStream_t st)
+void launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
     using Cfg = WCfg<WM>;
+    if (set_attr_only) {
+        (void)hipFuncSetAttribute((const void *)k_exchange_W<WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Cfg::SMEM_BYTES);
+        return;
+    }
     const int64_t outer = h->Ql * h->n_ntiles;
     const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
     hipLaunchKernelGGL(k_exchange_W<WM>, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
@@ -133,38 +138,17 @@ void launch_W_t(jcdf_handle *h, hipStream_t st)
                        h->opad, h->n_mtiles, h->n_ntiles);
 }
 
-template <int WM>
-void set_W_attr_t()
-{
-    (void)hipFuncSetAttribute((const void *)k_exchange_W<WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              WCfg<WM>::SMEM_BYTES);
-}
-
-void set_W_attr(int WM)
-{
-    switch (WM) {
-        case 1: set_W_attr_t<1>(); break;
-        case 2: set_W_attr_t<2>(); break;
-        case 3: set_W_attr_t<3>(); break;
-        case 4: set_W_attr_t<4>(); break;
-        case 5: set_W_attr_t<5>(); break;
-        case 6: set_W_attr_t<6>(); break;
-        case 7: set_W_attr_t<7>(); break;
-        default: set_W_attr_t<8>(); break;
-    }
-}
-
-void launch_W(jcdf_handle *h, hipStream_t st)
+void launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
     switch (h->WMw) {
-        case 1: launch_W_t<1>(h, st); break;
-        case 2: launch_W_t<2>(h, st); break;
-        case 3: launch_W_t<3>(h, st); break;
-        case 4: launch_W_t<4>(h, st); break;
-        case 5: launch_W_t<5>(h, st); break;
-        case 6: launch_W_t<6>(h, st); break;
-        case 7: launch_W_t<7>(h, st); break;
-        default: launch_W_t<8>(h, st); break;
+        case 1: launch_W_t<1>(h, st, attr); break;
+        case 2: launch_W_t<2>(h, st, attr); break;
+        case 3: launch_W_t<3>(h, st, attr); break;
+        case 4: launch_W_t<4>(h, st, attr); break;
+        case 5: launch_W_t<5>(h, st, attr); break;
+        case 6: launch_W_t<6>(h, st, attr); break;
+        case 7: launch_W_t<7>(h, st, attr); break;
+        default: launch_W_t<8>(h, st, attr); break;
     }
 }
 
@@ -192,14 +176,14 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_prep_C", st);
         const int64_t tot = h->Np * h->opad;
         hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
-                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->dCpad, h->dCperm);
+                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles, h->dCpad, h->dCperm);
         r.alg_bytes = 8.0 * N * o;
         (void)hipEventRecord(r.e1, st);
     }
     {
         KernelRec &r = rec_begin(h, k++, "k_exchange_W", st);
         launch_W(h, st);
-        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)h->opad;
+        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)(h->n_mtiles * h->WMw * 16 + h->rv);
         r.alg_flops = 2.0 * Ql * N * N * o + 2.0 * Ql * N * o;      // W (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
         (void)hipEventRecord(r.e1, st);
@@ -441,9 +425,10 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     // orbital (M) tiling of the W kernel: <= 128 orbitals per workgroup, balanced
     h->n_mtiles = (int)((n_occ + 127) / 128);
     h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
+    h->rv = 0;
     h->opad = h->n_mtiles * h->WMw * 16;
     h->nvp = h->n_ntiles * h->n_mtiles;
-    set_W_attr(h->WMw);
+    launch_W(h, nullptr, true);
     // K: lower block-triangle of 128x128 tiles, split-K so that one wave of workgroups fills the chip
     const int nT = h->n_ntiles;
     h->ntri = nT * (nT + 1) / 2;

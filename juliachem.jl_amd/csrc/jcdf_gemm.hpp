@@ -27,13 +27,16 @@ namespace jcdf {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-template <int WM_, int WN_, int WAVES_M_, int WAVES_N_, int KC_>
+// A_EXTRA: additional A columns (beyond the MFMA rows) staged into LDS for a VALU side
+// computation done by the `extra` hook (multiple of 2).
+template <int WM_, int WN_, int WAVES_M_, int WAVES_N_, int KC_, int A_EXTRA_ = 0>
 struct GemmCfg {
     static constexpr int WM = WM_, WN = WN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, KC = KC_;
-    static constexpr int TM = 16 * WM * WAVES_M;
+    static constexpr int TM_MFMA = 16 * WM * WAVES_M;
+    static constexpr int TM = TM_MFMA + A_EXTRA_;                 // staged A width
     static constexpr int TN = 16 * WN * WAVES_N;
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
-    static constexpr int LDAS = TM + ((TM % 32 == 16) ? 0 : 16);   // doubles; stride*8 % 256 == 128
+    static constexpr int LDAS = ((TM + 15) / 32) * 32 + 16;       // doubles; >= TM and stride*8 % 256 == 128
     static constexpr int LDBS = TN + ((TN % 32 == 16) ? 0 : 16);
     static constexpr int STAGE_DOUBLES = KC * (LDAS + LDBS);
     static constexpr int SMEM_BYTES = 2 * STAGE_DOUBLES * 8;
@@ -51,11 +54,19 @@ struct GemmCfg {
 // ABL: timing-only ablation bits for tools/w_ablate.hip (0 in the product):
 //   1 = no A global loads after the first stage, 2 = no B global loads after the first
 //   stage, 4 = no LDS re-staging (ds_write) after the first stage, 8 = no barrier in the loop.
-template <class Cfg, bool STREAM_B, int ABL = 0>
+struct NoExtra {
+    __device__ __forceinline__ void operator()(const double *, const double *) const {}
+};
+
+// `extra(As, Bs)` is called once per LDS stage (KC rows; As row stride Cfg::LDAS, Bs row
+// stride Cfg::LDBS) between the MFMAs and the re-staging.
+// PREFETCH = 2: two register sets, every global load has two compute phases to land (for the
+// HBM-streaming W kernel); PREFETCH = 1: one set (operands served from L2, fewer VGPRs).
+template <class Cfg, bool STREAM_B, int ABL = 0, int PREFETCH = 1, class Extra = NoExtra>
 __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int64_t lda,
                                              const double *__restrict__ Bg, int64_t ldb,
                                              int nchunks, double4_t (&acc)[Cfg::WM][Cfg::WN],
-                                             double *smem)
+                                             double *smem, Extra extra = Extra())
 {
     constexpr int WM = Cfg::WM, WN = Cfg::WN, KC = Cfg::KC;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
@@ -69,10 +80,14 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
     const int lr = lane & 15;   // row (A) / col (B) inside the MFMA tile
     const int lk = lane >> 4;   // k inside the MFMA step
 
-    double2_t ra[Cfg::A_PER_THREAD];
-    double2_t rb[Cfg::B_PER_THREAD];
+    // Two register sets: the loads of stage t+2 are issued before the MFMAs of stage t and are
+    // written to LDS after the MFMAs of stage t+1, i.e. every global load has two full compute
+    // phases to land.  (With one set the W kernel was latency-bound: replacing 1/6 of its MFMAs
+    // by nothing did not make it faster; HBM latency under this load is ~3 us.)
+    double2_t ra0[Cfg::A_PER_THREAD], rb0[Cfg::B_PER_THREAD];
+    double2_t ra1[Cfg::A_PER_THREAD], rb1[Cfg::B_PER_THREAD];
 
-    auto load_stage = [&](int chunk) {
+    auto load_stage = [&](double2_t (&ra)[Cfg::A_PER_THREAD], double2_t (&rb)[Cfg::B_PER_THREAD], int chunk) {
         const double *Ap = Ag + (int64_t)chunk * KC * lda;
         const double *Bp = Bg + (int64_t)chunk * KC * ldb;
         if (!((ABL & 1) && chunk > 0))
@@ -95,7 +110,7 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
             }
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](const double2_t (&ra)[Cfg::A_PER_THREAD], const double2_t (&rb)[Cfg::B_PER_THREAD], int buf) {
         double *As = smem + buf * Cfg::STAGE_DOUBLES;
         double *Bs = As + KC * LDAS;
 #pragma unroll
@@ -115,18 +130,9 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
             }
         }
     };
-
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-
-    int cur = 0;
-    for (int t = 0; t < nchunks; ++t) {
-        const bool more = (t + 1 < nchunks);
-        if (more) load_stage(t + 1);          // HBM/L2 latency hides under this chunk's MFMAs
-
-        const double *As = smem + cur * Cfg::STAGE_DOUBLES + wm * (WM * 16) + lr;
-        const double *Bs = smem + cur * Cfg::STAGE_DOUBLES + KC * LDAS + wn * (WN * 16) + lr;
+    auto compute_stage = [&](int buf) {
+        const double *As = smem + buf * Cfg::STAGE_DOUBLES + wm * (WM * 16) + lr;
+        const double *Bs = smem + buf * Cfg::STAGE_DOUBLES + KC * LDAS + wn * (WN * 16) + lr;
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             double a[WM], b[WN];
@@ -140,10 +146,38 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
                 for (int n = 0; n < WN; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
         }
+        extra(smem + buf * Cfg::STAGE_DOUBLES, smem + buf * Cfg::STAGE_DOUBLES + KC * LDAS);
+    };
 
-        if (more && !(ABL & 4)) store_stage(cur ^ 1);   // other buffer: last read before the previous barrier
-        if (!(ABL & 8)) __syncthreads();
-        if (!(ABL & 4)) cur ^= 1;
+    load_stage(ra0, rb0, 0);
+    store_stage(ra0, rb0, 0);
+    if (PREFETCH == 2) {
+        if (nchunks > 1) load_stage(ra1, rb1, 1);
+        __syncthreads();
+        for (int t = 0; t < nchunks; t += 2) {
+            // even stage t: LDS buffer 0; set 1 holds stage t+1 (in flight); set 0 is free
+            if (t + 2 < nchunks) load_stage(ra0, rb0, t + 2);
+            compute_stage(0);
+            if (t + 1 < nchunks && !(ABL & 4)) store_stage(ra1, rb1, 1);   // buffer 1: last read before the previous barrier
+            if (!(ABL & 8)) __syncthreads();
+            if (t + 1 >= nchunks) break;
+            // odd stage t+1: LDS buffer 1; set 0 holds stage t+2 (in flight); set 1 is free
+            if (t + 3 < nchunks) load_stage(ra1, rb1, t + 3);
+            compute_stage((ABL & 4) ? 0 : 1);
+            if (t + 2 < nchunks && !(ABL & 4)) store_stage(ra0, rb0, 0);
+            if (!(ABL & 8)) __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        int cur = 0;
+        for (int t = 0; t < nchunks; ++t) {
+            const bool more = (t + 1 < nchunks);
+            if (more) load_stage(ra0, rb0, t + 1);      // latency hides under this stage's MFMAs
+            compute_stage(cur);
+            if (more && !(ABL & 4)) store_stage(ra0, rb0, cur ^ 1);   // other buffer: last read before the previous barrier
+            if (!(ABL & 8)) __syncthreads();
+            if (!(ABL & 4)) cur ^= 1;
+        }
     }
 }
 

@@ -28,7 +28,7 @@ constexpr int TILE_P = 128;     // p-tile of every MFMA kernel == padding unit o
 //   Cperm[mt][ct][t][lane][e] = C[p = 16 ct + (lane&15)][i = mt*TMw + 16 (t/2) + (lane>>4) + 4 (2 (t&1) + e)]
 // (ct = 16-column tile, t < 2*WMw, e < 2), i.e. element e of lane's t-th double2
 // pairs with accumulator acc[m = t/2][.][j = 2 (t&1) + e].
-__global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int opad, int WMw,
+__global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int opad, int WMw, int n_mtiles,
                          double *__restrict__ Cpad, double *__restrict__ Cperm)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,6 +37,7 @@ __global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int
     const double v = (q < N && i < o) ? C[q + (int64_t)N * i] : 0.0;
     Cpad[idx] = v;
     const int TMw = 16 * WMw;
+    if (i >= TMw * n_mtiles) return;                      // remainder orbitals (VALU path) are not in Cperm
     const int mt = i / TMw, il = i % TMw;
     const int m = il >> 4, lk = il & 3, j = (il & 15) >> 2;
     const int t = 2 * m + (j >> 1), e = j & 1;
@@ -56,10 +57,13 @@ __global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int
 // are co-resident per CU, so the two waves sharing a SIMD's matrix pipe belong to
 // different workgroups and do not hit their barriers together.
 // Variants measured in one process on the C20H42 shape (tools/w_ablate.hip,
-// profiles/r01_w_ablate.txt): this one 61 TF executed; 8 waves x (WM x 1) 59 TF;
+// profiles/r01_w_ablate.txt): this one 57-61 TF executed; 8 waves x (WM x 1) 59 TF;
 // 8 waves, 256 columns 54 TF; B fragments loaded straight from HBM into registers
-// (no LDS for B, barrier every 32 rows) 55-56 TF; MFMA + ds_read only (no loads,
-// no barrier) 70 TF = the ceiling of this loop at the clock the chip holds.
+// (no LDS for B, barrier every 32 rows) 55-58 TF; MFMA + ds_read only (no loads,
+// no barrier) 70 TF = the ceiling of this loop at the ~2.1 GHz the chip holds.
+// The kernel is not MFMA-issue-bound: doing 80 of the 81 orbitals of C20H42 with 5
+// MFMA row tiles and the 81st with VALU FMAs (1/6 fewer MFMAs) did not make it faster,
+// so n_occ is simply padded to a multiple of 16.
 // ---------------------------------------------------------------------------
 template <int WM>
 using WCfg = GemmCfg<WM, 2, 1, 4, KC>;
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
 #pragma unroll
     for (int m = 0; m < WM; ++m) acc[m][0] = acc[m][1] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    const double *Ag = Cpad + mt * Cfg::TM;
+    const double *Ag = Cpad + mt * Cfg::TM_MFMA;
     const double *Bg = B + (int64_t)Q * Nk * Np + nt * Cfg::TN;
-    gemm_tn_core<Cfg, true>(Ag, opad, Bg, Np, Nk / KC, acc, smem);
+    gemm_tn_core<Cfg, true, 0, 2>(Ag, opad, Bg, Np, Nk / KC, acc, smem);
 
     double vsum = 0.0;
 #pragma unroll
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
         for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int i = mt * Cfg::TM + tile_row<Cfg>(m, j);
+                const int i = mt * Cfg::TM_MFMA + tile_row<Cfg>(m, j);
                 if (i < o) W[((int64_t)Q * o + i) * Np + p] = acc[m][n][j];
             }
     }

@@ -9,7 +9,7 @@
 #include <vector>
 using namespace jcdf;
 
-template <class Cfg, int ABL, int MINW>
+template <class Cfg, int ABL, int MINW, int PF = 1>
 __global__ __launch_bounds__(Cfg::NT, MINW) void k_w_lds(const double *__restrict__ B, const double *__restrict__ Cpad,
                                                            double *__restrict__ W, int Ql, int o, int Nk, int Np, int opad,
                                                            int n_ntiles)
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(Cfg::NT, MINW) void k_w_lds(const double *__restric
     double4_t acc[Cfg::WM][Cfg::WN];
     for (int m = 0; m < Cfg::WM; ++m)
         for (int n = 0; n < Cfg::WN; ++n) acc[m][n] = double4_t{0, 0, 0, 0};
-    gemm_tn_core<Cfg, true, ABL>(Cpad, opad, B + (int64_t)Q * Nk * Np + nt * Cfg::TN, Np, Nk / Cfg::KC, acc, smem);
+    gemm_tn_core<Cfg, true, ABL, PF>(Cpad, opad, B + (int64_t)Q * Nk * Np + nt * Cfg::TN, Np, Nk / Cfg::KC, acc, smem);
     for (int n = 0; n < Cfg::WN; ++n) {
         const int p = nt * Cfg::TN + tile_col<Cfg>(n);
         for (int m = 0; m < Cfg::WM; ++m)
@@ -157,11 +157,11 @@ int main(int argc, char **argv)
     {   // the product kernel itself (XCD decode, fused V epilogue)
         using Cfg = WCfg<6>;
         hipFuncSetAttribute((const void *)k_exchange_W<6>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
+        hipFuncSetAttribute((const void *)k_exchange_W<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
         const int nnt = Np / Cfg::TN;
         const int nblk = ((Ql * nnt + 7) / 8) * 8;
-        hipFuncSetAttribute((const void *)k_exchange_W<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
-        vs.push_back({"PRODUCT without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, false>), dim3(nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
-        vs.push_back({"PRODUCT k_exchange_W<6>", [=] { hipLaunchKernelGGL((k_exchange_W<6>), dim3(nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
+        vs.push_back({"PRODUCT k_exchange_W<6> without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, false>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
+        vs.push_back({"PRODUCT k_exchange_W<6>", [=] { hipLaunchKernelGGL((k_exchange_W<6>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
     }
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>; using I15 = std::integral_constant<int, 15>;
