@@ -173,6 +173,16 @@ def main():
         w_avg = w["seconds"] / w["n"]
         w_alg = w["alg_flops"]                  # algorithmic flops of ONE launch (this rank's aux shard)
         achieved = w_alg / w_avg / 1e12
+        # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, tools/collect_round_profiles.sh;
+        # (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md): valid for the 1-GPU workload
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.config == "C20H42" and os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf))["k_exchange_W"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of tools/prof_fock.py, same kernel and shape)"
+            except Exception:
+                traffic = None
         out = {
             "metric": "SCF iterations/sec (DF-RHF, C20H42/cc-pVDZ shape); Fock-build TFLOP/s in fock_build_tflops",
             "value": args.steps / elapsed, "unit": "SCF iterations/s", "n_gpus": world, "steps": args.steps,
@@ -187,7 +197,8 @@ def main():
             "setup_s": t_setup,
             "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in kstats.items()},
             "roofline": {"kernel": "k_exchange_W", "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src, "alg_bytes_per_launch": w["alg_bytes"],
                          "launch_ms": w_avg * 1e3, "alg_flops_per_launch": w_alg,
                          "executed_tflops": w["flops"] / w_avg / 1e12,
                          "alg_hbm_GBs": w["alg_bytes"] / w_avg / 1e9,

@@ -279,9 +279,12 @@ int32_t push_block(jcdf_handle *h, int64_t s0, int64_t s1, const double *T, bool
         launch_scatter(h, h->dRaw, R, h->dTint);
         const int n_xtiles = (int)(slab / MCfg::TN);
         const int n_mt = (int)(roundup(h->Ql, MCfg::TM) / MCfg::TM);
-        hipLaunchKernelGGL(k_metric_apply, dim3((unsigned)(n_xtiles * n_mt)), dim3(MCfg::NT), MCfg::SMEM_BYTES,
-                           h->stream, h->dLinvT + (s0 + a0) * h->ldl, h->ldl, h->dTint, slab, (int)Kpad,
-                           (int)h->Ql, n_xtiles, h->dB);
+        // L^-1 is lower triangular: rows of this shard above the block's first column get nothing
+        const int mt0 = (int)(std::max<int64_t>(0, s0 + a0 - h->q0) / MCfg::TM);
+        if (mt0 < n_mt)
+            hipLaunchKernelGGL(k_metric_apply, dim3((unsigned)(n_xtiles * (n_mt - mt0))), dim3(MCfg::NT),
+                               MCfg::SMEM_BYTES, h->stream, h->dLinvT + (s0 + a0) * h->ldl, h->ldl, h->dTint, slab,
+                               (int)Kpad, (int)h->Ql, n_xtiles, mt0, h->dB);
         if (!on_device) JCDF_HIP(h, hipStreamSynchronize(h->stream));   // host buffer may be reused by caller
     }
     hipError_t e = hipGetLastError();

@@ -329,12 +329,12 @@ using MCfg = GemmCfg<4, 2, 2, 4, KC>;
 
 __global__ __launch_bounds__(512) void k_metric_apply(
     const double *__restrict__ LinvT, int64_t ldl, const double *__restrict__ T, int64_t slab,
-    int Kpad, int M, int n_xtiles, double *__restrict__ Bout)
+    int Kpad, int M, int n_xtiles, int mt0, double *__restrict__ Bout)
 {
     using Cfg = MCfg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int xt = blockIdx.x % n_xtiles;
-    const int mt = blockIdx.x / n_xtiles;
+    const int mt = mt0 + blockIdx.x / n_xtiles;           // row tiles above the diagonal of L^-1 are skipped
 
     double4_t acc[Cfg::WM][Cfg::WN];
 #pragma unroll

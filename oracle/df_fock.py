@@ -177,12 +177,15 @@ def calculate_coulomb_dense(B: np.ndarray, C_occ: np.ndarray) -> Tuple[np.ndarra
 
 def calculate_exchange_dense(B: np.ndarray, C_occ: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """W[i,Q,mu] = sum_nu C[nu,i] B[Q,mu,nu] (gemm 'T','T', :216);
-    K = W^T W over (i,Q) (:219, applied with alpha=-1 onto F)."""
+    K = W^T W over (i,Q) (:219, applied with alpha=-1 onto F).
+    Written as the two large GEMMs of the reference (no einsum temporaries), so that the
+    timed CPU baseline is a fair restatement: (Q*N x N)(N x o), then (N x Q*o)(Q*o x N)."""
     Q, n, _ = B.shape
     o = C_occ.shape[1]
-    W = np.einsum("ni,qmn->iqm", C_occ, B, optimize=True)
-    W2 = W.reshape(o * Q, n)
-    return W2.T @ W2, W
+    W3 = (B.reshape(Q * n, n) @ C_occ).reshape(Q, n, o)          # W3[Q, mu, i]  (B symmetric in mu,nu)
+    Wm = np.ascontiguousarray(W3.transpose(1, 0, 2)).reshape(n, Q * o)
+    K = Wm @ Wm.T
+    return K, W3.transpose(2, 0, 1)                               # W as (o, Q, N), a view
 
 
 def df_rhf_fock_build_BLAS(B: np.ndarray, C_occ: np.ndarray) -> np.ndarray:
