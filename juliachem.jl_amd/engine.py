@@ -44,6 +44,30 @@ def shard_ranges(aux_shell_nbas: Sequence[int], n_shards: int) -> List[range]:
     return out
 
 
+def _staged(dist, t) -> bool:
+    """gloo cannot move device tensors: stage through the host (test/rehearsal path only;
+    the production backend is nccl == RCCL, which works on the device buffers directly)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _broadcast(dist, t, src: int) -> None:
+    if _staged(dist, t):
+        tmp = t.cpu()
+        dist.broadcast(tmp, src)
+        t.copy_(tmp)
+    else:
+        dist.broadcast(t, src)
+
+
+def _all_reduce(dist, t) -> None:
+    if _staged(dist, t):
+        tmp = t.cpu()
+        dist.all_reduce(tmp)
+        t.copy_(tmp)
+    else:
+        dist.all_reduce(t)
+
+
 def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int, dist, T_own, alloc, push) -> None:
     """One-time B formation across ranks (reference: GPUDF.jl:918-997, host-staged
     MPI.Send/Recv!).  Every rank owns the three-centre integrals of its own aux rows;
@@ -57,7 +81,7 @@ def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int,
             blk = T_own
         else:
             blk = T_own if s == rank else alloc(len(rows) * P)
-            dist.broadcast(blk, s)
+            _broadcast(dist, blk, s)
         push(rows.start, rows.stop, blk)
 
 
@@ -65,7 +89,7 @@ def allreduce_fock(F, world: int, dist):
     """Sum of the per-shard partial Fock matrices: MPI.Allreduce!(two_electron_fock)
     of DensityFitting.jl:68-71 as ONE collective on the N x N buffer."""
     if world > 1:
-        dist.all_reduce(F)
+        _all_reduce(dist, F)
     return F
 
 
