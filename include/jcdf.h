@@ -163,6 +163,16 @@ int32_t jcdf_get_W(jcdf_handle *h, double *W_out);
  * 1-based index of the first non-positive pivot.  Upper triangle is zeroed. */
 int32_t jcdf_host_potrf_trtri(double *A, int64_t n);
 
+/* Caller-side helper for the replicated eigensolve of the SCF iteration (reference: host
+ * LAPACK eigen!(Hermitian(.)) at src/rhf/energy/SCF.jl:1083): Householder tridiagonalisation
+ * (LAPACK dsytrd 'L' semantics: D, E, TAU and reflectors below the sub-diagonal of A, column-
+ * major) of the symmetric n x n device matrix d_A in ONE persistent kernel on `stream`.
+ * d_work: jcdf_sytrd_workspace_bytes(n) bytes of device memory; its int at byte offset 8 is
+ * non-zero afterwards if the in-kernel grid barrier timed out (result invalid).  n <~ 2200. */
+int64_t jcdf_sytrd_workspace_bytes(int64_t n);
+int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
+                          double *d_TAU, void *d_work, int64_t work_bytes);
+
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */
 int64_t jcdf_device_bytes(const jcdf_handle *h);

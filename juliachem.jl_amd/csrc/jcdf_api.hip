@@ -6,9 +6,11 @@
 #include "../../include/jcdf.h"
 #include "jcdf_kernels.hpp"
 #include "jcdf_host_lapack.hpp"
+#include "jcdf_eig.hpp"
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -680,6 +682,55 @@ int32_t jcdf_host_potrf_trtri(double *A, int64_t n)
 {
     if (!A || n <= 0) return -1;
     return hostlapack::potrf_trtri_lower(A, n);
+}
+
+// ---- replicated eigensolve helper (caller side) ----------------------------
+static int sytrd_groups(int64_t n, size_t *lds_bytes)
+{
+    // fewest workgroups that hold the matrix in LDS, but at least the measured sweet spot
+    // (tools/eigbench3.py: n = 240 -> 32, n = 510 -> 64 workgroups; flat between 32 and 128)
+    int G = n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1));
+    const char *env = getenv("JCDF_SYTRD_G");
+    for (;;) {
+        const size_t lds = (size_t)(((n + G - 1) / G) * n + 2 * n + 16) * 8;
+        if (lds <= 150 * 1024 || G >= 256) { *lds_bytes = lds; break; }
+        G *= 2;
+    }
+    if (env) {
+        const int want = atoi(env);
+        if (want >= G && want <= 256) {
+            G = want;
+            *lds_bytes = (size_t)(((n + G - 1) / G) * n + 2 * n + 16) * 8;
+        }
+    }
+    return G;
+}
+
+int64_t jcdf_sytrd_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    return 64 + (int64_t)(4 * n + 2 * 256 + 2) * 8;
+}
+
+int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
+                          void *d_work, int64_t work_bytes)
+{
+    if (n <= 0 || !d_A || lda < n || !d_D || !d_E || !d_TAU || !d_work || work_bytes < jcdf_sytrd_workspace_bytes(n))
+        return JCDF_ERR_INVALID;
+    size_t lds = 0;
+    const int G = sytrd_groups(n, &lds);
+    if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // n too large for LDS residency (n <~ 2200)
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)d_work;
+    unsigned long long *bar = (unsigned long long *)w;
+    int *err = (int *)(w + 8);
+    unsigned long long *vflag = (unsigned long long *)(w + 16);
+    double *vbuf = (double *)(w + 64), *ybuf = vbuf + 2 * n, *dots = ybuf + 2 * n;
+    if (hipMemsetAsync(w, 0, 64, st) != hipSuccess) return JCDF_ERR_HIP;
+    (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vbuf,
+                       ybuf, dots, bar, vflag, err);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }

@@ -1,0 +1,92 @@
+"""Replicated symmetric eigensolver of the SCF iteration (caller side of the hot path,
+SURVEY 8 row f1; reference: `eigen!(Hermitian(F'))`, SCF.jl:1083).
+
+rocSOLVER's syevd needs ~4000 tiny launches for the tridiagonalisation (9 of its 12 ms at
+N = 510).  Here the tridiagonalisation is ONE persistent kernel of libjcdf_hip.so
+(`jcdf_sytrd_device`, csrc/jcdf_eig.hpp) and only the remaining two LAPACK steps use the
+vendor library already in the process (PyTorch's librocsolver): stedc (divide & conquer on
+the tridiagonal matrix) and ormtr (back-transformation by the Householder reflectors).
+Falls back to torch.linalg.eigh when the vendor entry points are unavailable or the
+in-kernel grid barrier reports a timeout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_EVECT_TRIDIAGONAL = 212      # rocblas_evect_tridiagonal
+_SIDE_LEFT = 141              # rocblas_side_left
+_FILL_LOWER = 122             # rocblas_fill_lower
+_OP_NONE = 111                # rocblas_operation_none
+
+
+class DeviceEigh:
+    def __init__(self, n: int, device: torch.device):
+        self.n, self.device = n, device
+        self.ok = False
+        self.calls = self.fallbacks = 0
+        try:
+            tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+            self.rb = C.CDLL(os.path.join(tl, "librocblas.so"))
+            self.rs = C.CDLL(os.path.join(tl, "librocsolver.so"))
+            self.lib = _lib.load()
+            self.handle = C.c_void_p()
+            if self.rb.rocblas_create_handle(C.byref(self.handle)) != 0:
+                raise OSError("rocblas_create_handle failed")
+            f64 = dict(dtype=torch.float64, device=device)
+            self.A = torch.empty((n, n), **f64)
+            self.Cm = torch.empty((n, n), **f64)
+            self.D = torch.empty(n, **f64)
+            self.E = torch.empty(n, **f64)
+            self.TAU = torch.empty(n, **f64)
+            self.info = torch.zeros(1, dtype=torch.int32, device=device)
+            wb = int(self.lib.jcdf_sytrd_workspace_bytes(n))
+            self.work = torch.zeros(wb // 8 + 1, **f64)
+            self.wb = wb
+            self.ok = True
+        except Exception as e:                                    # vendor library not loadable: plain torch path
+            self.reason = repr(e)
+
+    def __call__(self, Fp: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Fp: symmetric (n, n) device tensor.  Returns (eigenvalues ascending, U with
+        eigenvectors in columns), like torch.linalg.eigh."""
+        self.calls += 1
+        if not self.ok:
+            return torch.linalg.eigh(Fp)
+        n = self.n
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.rb.rocblas_set_stream(self.handle, C.c_void_p(st))
+        self.A.copy_(Fp)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.jcdf_sytrd_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
+                                        p(self.work), self.wb)
+        if rc == 0:
+            rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
+                                          p(self.info))
+        if rc == 0:
+            rc = self.rs.rocsolver_dormtr(self.handle, _SIDE_LEFT, _FILL_LOWER, _OP_NONE, n, n, p(self.A), n,
+                                          p(self.TAU), p(self.Cm), n)
+        if rc != 0:
+            self.ok = False
+            self.reason = "vendor/library call failed rc=%d" % rc
+            self.fallbacks += 1
+            return torch.linalg.eigh(Fp)
+        # column-major eigenvector matrix == transpose of the row-major view
+        return self.D, self.Cm.T
+
+    def check(self) -> bool:
+        """True if the persistent kernel's grid barrier never timed out and stedc converged
+        (reads two words from the device: call where the stream is synchronised anyway)."""
+        if not self.ok:
+            return True
+        err = int(self.work[1:2].view(torch.int32)[0].item())       # int at byte offset 8
+        bad = err != 0 or int(self.info.item()) != 0
+        if bad:
+            self.ok = False
+            self.reason = "sytrd barrier timeout" if err else "stedc info=%d" % int(self.info.item())
+        return not bad
