@@ -144,6 +144,12 @@ int32_t jcdf_set_core_hamiltonian(jcdf_handle *h, const double *H);
  * 2J - K (+ H if set) — the contract of scf_data.two_electron_fock
  * (DensityFitting.jl:62-75).  t may be NULL. */
 int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t);
+/* The same in two halves, so that a host driving several handles (num_devices > 1,
+ * one Julia task per device at GPUDF.jl:188-193) overlaps the devices from one thread:
+ * begin() copies C_occ and enqueues the kernels and returns; finish() copies F back and
+ * synchronises.  jcdf_fock_build == begin + finish. */
+int32_t jcdf_fock_build_begin(jcdf_handle *h, const double *C_occ);
+int32_t jcdf_fock_build_finish(jcdf_handle *h, double *F_out, jcdf_timings *t);
 /* Same with device pointers on this handle's device.  Work is enqueued on
  * `stream` (a hipStream_t; NULL = the handle's stream, see jcdf_set_stream) and is
  * NOT synchronised on return, so the caller can chain an RCCL all-reduce of d_F. */

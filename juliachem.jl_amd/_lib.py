@@ -50,6 +50,8 @@ PROTOTYPES = {
     "jcdf_get_B": (C.c_int32, [_P, _P]),
     "jcdf_set_core_hamiltonian": (C.c_int32, [_P, _P]),
     "jcdf_fock_build": (C.c_int32, [_P, _P, _P, C.POINTER(jcdf_timings)]),
+    "jcdf_fock_build_begin": (C.c_int32, [_P, _P]),
+    "jcdf_fock_build_finish": (C.c_int32, [_P, _P, C.POINTER(jcdf_timings)]),
     "jcdf_fock_build_device": (C.c_int32, [_P, _P, _P, _P]),
     "jcdf_synchronize": (C.c_int32, [_P, C.POINTER(jcdf_timings)]),
     "jcdf_get_V": (C.c_int32, [_P, _P]),

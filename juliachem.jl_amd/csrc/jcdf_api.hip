@@ -55,6 +55,9 @@ struct jcdf_handle {
     double *dLinvT = nullptr;
     int64_t ldl = 0, linv_rows = 0;
     int64_t *dpq_p = nullptr, *dpq_q = nullptr;
+    int *dWkptr = nullptr, *dWklist = nullptr;          // block-sparse stage lists of the W kernel (null: dense)
+    unsigned long long *dJmask = nullptr;               // per J row block: non-empty 128-column tiles
+    double kept_tile_fraction = 1.0;
     double *dRaw = nullptr, *dTint = nullptr;      // setup staging (chunked), freed after setup
     int64_t stage_rows = 0;
     int64_t bytes = 0;
@@ -117,6 +120,9 @@ void free_all(jcdf_handle *h)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (h->dpq_p) { (void)hipFree(h->dpq_p); h->dpq_p = nullptr; }
     if (h->dpq_q) { (void)hipFree(h->dpq_q); h->dpq_q = nullptr; }
+    if (h->dWkptr) { (void)hipFree(h->dWkptr); h->dWkptr = nullptr; }
+    if (h->dWklist) { (void)hipFree(h->dWklist); h->dWklist = nullptr; }
+    if (h->dJmask) { (void)hipFree(h->dJmask); h->dJmask = nullptr; }
     for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     h->recs.clear();
     h->bytes = 0;
@@ -137,7 +143,7 @@ void launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
     hipLaunchKernelGGL(k_exchange_W<WM>, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
                        h->dCpad, h->dCperm, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
-                       h->opad, h->n_mtiles, h->n_ntiles);
+                       h->opad, h->n_mtiles, h->n_ntiles, h->dWkptr, h->dWklist);
 }
 
 void launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
@@ -185,7 +191,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     {
         KernelRec &r = rec_begin(h, k++, "k_exchange_W", st);
         launch_W(h, st);
-        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)(h->n_mtiles * h->WMw * 16 + h->rv);
+        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)(h->n_mtiles * h->WMw * 16) * h->kept_tile_fraction;
         r.alg_flops = 2.0 * Ql * N * N * o + 2.0 * Ql * N * o;      // W (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
         (void)hipEventRecord(r.e1, st);
@@ -194,7 +200,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_coulomb_J", st);
         hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)((h->N + J_ROWS - 1) / J_ROWS), (unsigned)h->SJ), dim3(256),
                            (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
-                           (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV);
+                           (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV, h->dJmask);
         r.flops = r.alg_flops = Ql * N * (N + 1.0);
         r.alg_bytes = 8.0 * Ql * N * (N + 1.0) / 2.0;               // lower triangle of B, once
         (void)hipEventRecord(r.e1, st);
@@ -424,6 +430,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
 
     h->N = N; h->Qtot = Q_total; h->q0 = q0; h->q1 = q1; h->Ql = q1 - q0; h->o = n_occ; h->P = P;
     h->dense_map = (pq_p == nullptr);
+    h->kept_tile_fraction = 1.0;
     h->Nk = roundup(N, KC);
     h->Np = roundup(N, TILE_P);
     h->n_ntiles = (int)(h->Np / TILE_P);
@@ -475,6 +482,34 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         if ((rc = dev_alloc(h, &h->dpq_q, P, false))) return rc;
         JCDF_HIP(h, hipMemcpyAsync(h->dpq_p, pq_p, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
         JCDF_HIP(h, hipMemcpyAsync(h->dpq_q, pq_q, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
+        // Block-sparse metadata from the packed (Schwarz-screened) pair list.  The pattern is the same
+        // for every aux index, so it is built once: for each 128-column tile the list of 16-row k
+        // stages that contain a kept pair (W kernel), and for each 8-row block the set of non-empty
+        // 128-column tiles (J kernel).  Everything else in B is exactly zero and is never read.
+        if (h->n_ntiles <= 64) {
+            const int nkc = (int)(h->Nk / KC), nrb = (int)((N + J_ROWS - 1) / J_ROWS);
+            std::vector<uint8_t> tile((size_t)nkc * h->n_ntiles, 0);
+            std::vector<unsigned long long> jm((size_t)nrb, 0ULL);
+            for (int64_t c = 0; c < P; ++c) {
+                const int64_t p = pq_p[c], q = pq_q[c];
+                tile[(size_t)(q / KC) * h->n_ntiles + (size_t)(p / TILE_P)] = 1;
+                if (p <= q) jm[(size_t)(q / J_ROWS)] |= 1ULL << (p / TILE_P);
+            }
+            std::vector<int> kptr((size_t)h->n_ntiles + 1, 0), klist;
+            for (int t = 0; t < h->n_ntiles; ++t) {
+                for (int kc = 0; kc < nkc; ++kc)
+                    if (tile[(size_t)kc * h->n_ntiles + t]) klist.push_back(kc);
+                kptr[(size_t)t + 1] = (int)klist.size();
+            }
+            h->kept_tile_fraction = (double)klist.size() / ((double)nkc * h->n_ntiles);
+            if ((rc = dev_alloc(h, &h->dWkptr, (int64_t)kptr.size(), false))) return rc;
+            if ((rc = dev_alloc(h, &h->dWklist, (int64_t)std::max<size_t>(klist.size(), 1), false))) return rc;
+            if ((rc = dev_alloc(h, &h->dJmask, (int64_t)jm.size(), false))) return rc;
+            JCDF_HIP(h, hipMemcpy(h->dWkptr, kptr.data(), kptr.size() * sizeof(int), hipMemcpyHostToDevice));
+            if (!klist.empty())
+                JCDF_HIP(h, hipMemcpy(h->dWklist, klist.data(), klist.size() * sizeof(int), hipMemcpyHostToDevice));
+            JCDF_HIP(h, hipMemcpy(h->dJmask, jm.data(), jm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
     }
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->configured = true;
@@ -632,22 +667,38 @@ int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t)
     return JCDF_OK;
 }
 
-int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t)
+int32_t jcdf_fock_build_begin(jcdf_handle *h, const double *C_occ)
 {
     if (!h) return JCDF_ERR_INVALID;
-    if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build: B not set");
-    if (!C_occ || !F_out) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build: NULL pointer");
+    if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_begin: B not set");
+    if (!C_occ) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_begin: NULL pointer");
     JCDF_HIP(h, hipSetDevice(h->device));
     if (h->stage_rows) release_stage(h);
     (void)hipEventRecord(h->ev_h2d, h->stream);
+    // pageable host memory: the copy has left the caller's buffer when this returns
     JCDF_HIP(h, hipMemcpyAsync(h->dC, C_occ, (size_t)(h->N * h->o) * 8, hipMemcpyHostToDevice, h->stream));
-    int32_t rc = enqueue_fock(h, h->dC, h->dF, h->stream);
-    if (rc) return rc;
+    return enqueue_fock(h, h->dC, h->dF, h->stream);
+}
+
+int32_t jcdf_fock_build_finish(jcdf_handle *h, double *F_out, jcdf_timings *t)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !F_out) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_finish: not configured / NULL");
+    JCDF_HIP(h, hipSetDevice(h->device));
     JCDF_HIP(h, hipMemcpyAsync(F_out, h->dF, (size_t)(h->N * h->N) * 8, hipMemcpyDeviceToHost, h->stream));
     (void)hipEventRecord(h->ev_d2h, h->stream);
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->timed_host_copy = true;
     return jcdf_synchronize(h, t);
+}
+
+int32_t jcdf_fock_build(jcdf_handle *h, const double *C_occ, double *F_out, jcdf_timings *t)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!F_out) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build: NULL pointer");
+    const int32_t rc = jcdf_fock_build_begin(h, C_occ);
+    if (rc) return rc;
+    return jcdf_fock_build_finish(h, F_out, t);
 }
 
 int32_t jcdf_get_V(jcdf_handle *h, double *V_out)

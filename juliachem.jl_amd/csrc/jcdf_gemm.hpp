@@ -66,8 +66,11 @@ template <class Cfg, bool STREAM_B, int ABL = 0, int PREFETCH = 1, class Extra =
 __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int64_t lda,
                                              const double *__restrict__ Bg, int64_t ldb,
                                              int nchunks, double4_t (&acc)[Cfg::WM][Cfg::WN],
-                                             double *smem, Extra extra = Extra())
+                                             double *smem, const int *__restrict__ klist = nullptr,
+                                             Extra extra = Extra())
 {
+    // klist (optional): stage t covers k rows [klist[t]*KC, +KC) instead of [t*KC, +KC) — block-sparse
+    // contraction: all-zero stages (fully Schwarz-screened tiles) are simply not in the list.
     constexpr int WM = Cfg::WM, WN = Cfg::WN, KC = Cfg::KC;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
     constexpr int LDAS = Cfg::LDAS, LDBS = Cfg::LDBS;
@@ -88,8 +91,9 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
     double2_t ra1[Cfg::A_PER_THREAD], rb1[Cfg::B_PER_THREAD];
 
     auto load_stage = [&](double2_t (&ra)[Cfg::A_PER_THREAD], double2_t (&rb)[Cfg::B_PER_THREAD], int chunk) {
-        const double *Ap = Ag + (int64_t)chunk * KC * lda;
-        const double *Bp = Bg + (int64_t)chunk * KC * ldb;
+        const int kc = klist ? klist[chunk] : chunk;
+        const double *Ap = Ag + (int64_t)kc * KC * lda;
+        const double *Bp = Bg + (int64_t)kc * KC * ldb;
         if (!((ABL & 1) && chunk > 0))
 #pragma unroll
         for (int i = 0; i < Cfg::A_PER_THREAD; ++i) {

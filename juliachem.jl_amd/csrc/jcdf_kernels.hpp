@@ -72,7 +72,7 @@ template <int WM, bool FUSE_V = true>
 __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
     const double *__restrict__ B, const double *__restrict__ Cpad, const double *__restrict__ Cperm,
     double *__restrict__ W, double *__restrict__ vpart, int Ql, int o, int Nk, int Np, int opad,
-    int n_mtiles, int n_ntiles)
+    int n_mtiles, int n_ntiles, const int *__restrict__ kptr, const int *__restrict__ klist)
 {
     using Cfg = WCfg<WM>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
 
     const double *Ag = Cpad + mt * Cfg::TM_MFMA;
     const double *Bg = B + (int64_t)Q * Nk * Np + nt * Cfg::TN;
-    gemm_tn_core<Cfg, true, 0, 2>(Ag, opad, Bg, Np, Nk / KC, acc, smem);
+    // block sparsity: only the 16-row k stages in which this column tile has a kept (q,p) pair
+    // (the Schwarz pattern does not depend on the aux index); dense map: all of them (kptr == null)
+    const int k0 = kptr ? kptr[nt] : 0;
+    const int nk = kptr ? kptr[nt + 1] - k0 : Nk / KC;
+    if (nk > 0) gemm_tn_core<Cfg, true, 0, 2>(Ag, opad, Bg, Np, nk, acc, smem, kptr ? klist + k0 : nullptr);
 
     double vsum = 0.0;
 #pragma unroll
@@ -137,7 +141,7 @@ constexpr int J_QUNROLL = 2;   // aux indices in flight per thread (x J_ROWS loa
 
 __global__ __launch_bounds__(256) void k_coulomb_J(
     const double *__restrict__ B, const double *__restrict__ vpart, int nvp, int Ql, int Nk, int Np,
-    int QS, double *__restrict__ Jpart, double *__restrict__ V)
+    int QS, double *__restrict__ Jpart, double *__restrict__ V, const unsigned long long *__restrict__ jmask)
 {
     extern __shared__ __attribute__((aligned(16))) double Vs[];
     const int q0 = blockIdx.x * J_ROWS;
@@ -160,7 +164,10 @@ __global__ __launch_bounds__(256) void k_coulomb_J(
     const int64_t slab2 = (int64_t)Nk * Np / 2;             // slab stride in double2 units
     const int np2 = Np / 2;
     const int qlast = q0 + J_ROWS - 1;
+    // jmask[row block]: bit t set <=> the 128-column tile t has a kept pair in these rows (null: dense)
+    const unsigned long long tmask = jmask ? jmask[blockIdx.x] : ~0ULL;
     for (int c2 = threadIdx.x; 2 * c2 <= qlast && c2 < np2; c2 += blockDim.x) {
+        if (!((tmask >> (c2 >> 6)) & 1ULL)) continue;      // whole tile screened: its Jpart stays 0
         const double2_t *ptr = reinterpret_cast<const double2_t *>(B) + ((int64_t)Qb * Nk + q0) * np2 + c2;
         double2_t acc[J_ROWS];
 #pragma unroll

@@ -406,6 +406,18 @@ class JCDFHandle:
         self._check(self._lib.jcdf_fock_build(self._h, c.ctypes.data, F.ctypes.data, C.byref(t)))
         return F, t
 
+    def fock_build_begin(self, C_occ: np.ndarray) -> None:
+        c = _f64(C_occ)
+        if self.N and c.shape != (self.N, self.o):
+            raise JCDFError(1, "C_occ has shape %s, expected (N, n_occ) = %s" % (c.shape, (self.N, self.o)))
+        self._check(self._lib.jcdf_fock_build_begin(self._h, c.ctypes.data))
+
+    def fock_build_finish(self) -> Tuple[np.ndarray, jcdf_timings]:
+        F = np.empty((self.N, self.N), dtype=np.float64, order="F")
+        t = jcdf_timings()
+        self._check(self._lib.jcdf_fock_build_finish(self._h, F.ctypes.data, C.byref(t)))
+        return F, t
+
     def fock_build_device(self, d_C_occ: int, d_F: int, stream: int = 0) -> None:
         self._check(self._lib.jcdf_fock_build_device(self._h, d_C_occ, d_F, stream or None))
 
@@ -591,7 +603,7 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
             rows = ranges[rank * num_devices + dev]
             if len(rows) == 0:
                 raise JCDFError(1, "more devices than auxiliary shells: empty shard")
-            h = JCDFHandle(dev if n_ranks == 1 else _local_device(dev, num_devices))
+            h = JCDFHandle(_physical_device(dev if n_ranks == 1 else _local_device(dev, num_devices)))
             h.configure(n, scf_data.A, rows.start, rows.stop, n_occ, pq[0], pq[1])
             h.set_core_hamiltonian(H if (rank == 0 and dev == 0) else None)   # GPUDF.jl:158-161
             gd.handles.append(h)
@@ -604,8 +616,10 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
     t0 = time.perf_counter()
     total = None
     per_dev: List[jcdf_timings] = []
-    for h in gd.handles:                       # devices of this process; kernels of one handle are async
-        F, t = h.fock_build(occupied_orbital_coefficients)
+    for h in gd.handles:                       # all devices of this process work concurrently (GPUDF.jl:188-193)
+        h.fock_build_begin(occupied_orbital_coefficients)
+    for h in gd.handles:
+        F, t = h.fock_build_finish()
         per_dev.append(t)
         total = F if total is None else total + F          # host reduce over devices, GPUDF.jl:273-276
     scf_data.two_electron_fock = total
@@ -622,6 +636,16 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
         jc_timing.timings[JCTiming_key(key, iteration)] = max(getattr(t, attr) for t in per_dev)
     jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_H_add_time, 1, iteration)] = per_dev[0].H_add_time
     jc_timing.timings[JCTiming_key(JCTC.fock_gpu_cpu_copy_reduce_time, iteration)] = max(t.copy_time for t in per_dev)
+
+
+def _physical_device(index: int) -> int:
+    """Test hook: with JCDF_ALLOW_DEVICE_WRAP=1 logical devices wrap onto the physical ones, so the
+    num_devices > 1 code path can be exercised on a one-GPU box (each handle is still one shard)."""
+    import os
+    if os.environ.get("JCDF_ALLOW_DEVICE_WRAP") == "1":
+        import torch
+        return index % max(1, torch.cuda.device_count())
+    return index
 
 
 def _local_device(dev: int, num_devices: int) -> int:

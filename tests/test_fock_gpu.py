@@ -319,3 +319,26 @@ def test_device_eigh_matches_lapack(n):
     assert np.abs(w - wref).max() < 1e-12 * scale * n
     assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
     assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
+
+
+def test_operator_with_two_devices_in_one_process(monkeypatch):
+    """num_devices = 2 (the reference's one-rank-many-GPUs mode, GPUDF.jl:188-277): two handles,
+    two aux shards, concurrent begin/finish, host reduce — wrapped onto the one physical GPU."""
+    monkeypatch.setenv("JCDF_ALLOW_DEVICE_WRAP", "1")
+    N, Q, o = 70, 113, 9
+    s = synthetic.make(N, Q, o, seed=8, kept_fraction=0.6)
+    bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes([N], nels=2 * o),
+                                 jc.basis_from_shell_sizes(s.aux_shell_nbas))
+    eng = jc.TensorIntegralEngine(s.J2c, s.T, mask=s.mask)
+    opts = jc.create_scf_options({"scf_type": "df", "contraction_mode": "GPU", "num_devices": 2,
+                                  "df_use_adaptive": False})
+    scf_data = jc.SCFData(jc.get_default_gpu_data_hip())
+    tm = jc.create_jctiming()
+    F = jc.df_rhf_fock_build(scf_data, eng, None, bs, s.C, 1, opts, s.H, tm)
+    sd = orc.get_screening_metadata(s.mask)
+    Bp = orc.pack_three_center(orc.calculate_B(s.J2c, s.T), sd)
+    ref = s.H + orc.df_rhf_fock_build_screened(Bp, s.C[:, :o], sd)
+    assert _rel(F, ref) < RTOL
+    assert len(scf_data.gpu_data.handles) == 2 and tm.non_timing_data["contraction_algorithm"] == "screened hip"
+    assert "GPU_2_W_time-1" in tm.timings and tm.non_timing_data["GPU_num_devices"] == "2"
+    scf_data.gpu_data.close()

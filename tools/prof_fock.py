@@ -15,10 +15,17 @@ from juliachem_jl_amd.engine import DeviceFockBuilder
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C20H42"
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+kept = float(sys.argv[3]) if len(sys.argv) > 3 else None      # Schwarz-kept pair fraction (band mask); None = dense map
 N, Q, o = synthetic.CONFIGS[cfg]
 rng = np.random.default_rng(1)
 dev = torch.device("cuda", 0)
-fb = DeviceFockBuilder(N, Q, o, [1] * Q, device=0)
+pq = (None, None)
+if kept is not None:
+    sd = jc.get_screening_metadata(synthetic.band_mask(N, kept, rng))
+    pq = jc.packed_pq_lists(sd)
+    print("screened map: kept pair fraction %.3f (P = %d of %d)" % (sd.screened_indices_count / N ** 2, sd.screened_indices_count, N * N))
+    sel = torch.as_tensor(pq[0] * N + pq[1], device=dev)
+fb = DeviceFockBuilder(N, Q, o, [1] * Q, device=0, pq=pq)
 fb.h.set_metric_inverse(np.eye(Q))            # B == T: setup cost is irrelevant here
 Hs = rng.standard_normal((N, N))
 fb.set_core_hamiltonian(0.5 * (Hs + Hs.T))
@@ -27,7 +34,8 @@ step = 256
 for s0 in range(0, Q, step):
     s1 = min(Q, s0 + step)
     A = torch.randn((N, N, s1 - s0), dtype=torch.float64, device=dev, generator=g) * 0.1
-    T = (0.5 * (A + A.transpose(0, 1))).contiguous().reshape(-1)
+    T = (0.5 * (A + A.transpose(0, 1))).contiguous()
+    T = T.reshape(N * N, s1 - s0)[sel].contiguous().reshape(-1) if kept is not None else T.reshape(-1)
     fb.push_three_center_device(s0, s1, T)
 torch.cuda.synchronize()
 C, _ = np.linalg.qr(rng.standard_normal((N, N)))
