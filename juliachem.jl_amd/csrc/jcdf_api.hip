@@ -42,7 +42,7 @@ struct jcdf_handle {
     // sizes
     int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
     int64_t Nk = 0, Np = 0;
-    int WMw = 0, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0, rv = 0;
+    int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0, rv = 0;
     int ntri = 0, S = 0, KS = 0;
     int SJ = 0, QS = 0;
     int64_t Wrows = 0;
@@ -129,34 +129,43 @@ void free_all(jcdf_handle *h)
     h->configured = h->have_metric = h->have_B = h->have_H = h->pushed_any = false;
 }
 
-// ---- W kernel dispatch over the number of 16-orbital MFMA row tiles -------------
-template <int WM>
+// ---- W kernel dispatch: WMw 16-orbital MFMA row tiles per wave, WVMw wave rows ------------
+template <int WM, int WVM>
 void launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
-    using Cfg = WCfg<WM>;
+    using Cfg = WCfg<WM, WVM>;
     if (set_attr_only) {
-        (void)hipFuncSetAttribute((const void *)k_exchange_W<WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_exchange_W<WM, WVM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Cfg::SMEM_BYTES);
         return;
     }
     const int64_t outer = h->Ql * h->n_ntiles;
     const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
-    hipLaunchKernelGGL(k_exchange_W<WM>, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
+    hipLaunchKernelGGL((k_exchange_W<WM, WVM>), dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
                        h->dCpad, h->dCperm, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
                        h->opad, h->n_mtiles, h->n_ntiles, h->dWkptr, h->dWklist);
 }
 
 void launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
+    if (h->WVMw == 2) {
+        switch (h->WMw) {
+            case 5: launch_W_t<5, 2>(h, st, attr); break;
+            case 6: launch_W_t<6, 2>(h, st, attr); break;
+            case 7: launch_W_t<7, 2>(h, st, attr); break;
+            default: launch_W_t<8, 2>(h, st, attr); break;
+        }
+        return;
+    }
     switch (h->WMw) {
-        case 1: launch_W_t<1>(h, st, attr); break;
-        case 2: launch_W_t<2>(h, st, attr); break;
-        case 3: launch_W_t<3>(h, st, attr); break;
-        case 4: launch_W_t<4>(h, st, attr); break;
-        case 5: launch_W_t<5>(h, st, attr); break;
-        case 6: launch_W_t<6>(h, st, attr); break;
-        case 7: launch_W_t<7>(h, st, attr); break;
-        default: launch_W_t<8>(h, st, attr); break;
+        case 1: launch_W_t<1, 1>(h, st, attr); break;
+        case 2: launch_W_t<2, 1>(h, st, attr); break;
+        case 3: launch_W_t<3, 1>(h, st, attr); break;
+        case 4: launch_W_t<4, 1>(h, st, attr); break;
+        case 5: launch_W_t<5, 1>(h, st, attr); break;
+        case 6: launch_W_t<6, 1>(h, st, attr); break;
+        case 7: launch_W_t<7, 1>(h, st, attr); break;
+        default: launch_W_t<8, 1>(h, st, attr); break;
     }
 }
 
@@ -184,14 +193,14 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_prep_C", st);
         const int64_t tot = h->Np * h->opad;
         hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
-                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles, h->dCpad, h->dCperm);
+                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles * h->WVMw, h->dCpad, h->dCperm);
         r.alg_bytes = 8.0 * N * o;
         (void)hipEventRecord(r.e1, st);
     }
     {
         KernelRec &r = rec_begin(h, k++, "k_exchange_W", st);
         launch_W(h, st);
-        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)(h->n_mtiles * h->WMw * 16) * h->kept_tile_fraction;
+        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)h->opad * h->kept_tile_fraction;
         r.alg_flops = 2.0 * Ql * N * N * o + 2.0 * Ql * N * o;      // W (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
         (void)hipEventRecord(r.e1, st);
@@ -208,8 +217,13 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     {
         KernelRec &r = rec_begin(h, k++, "k_exchange_K", st);
         const int nblk = (int)(roundup(h->S, 8) * h->ntri);
-        hipLaunchKernelGGL(k_exchange_K, dim3((unsigned)nblk), dim3(KCfg::NT), KCfg::SMEM_BYTES, st, h->dW,
-                           (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
+        static const bool k4 = [] { const char *e = getenv("JCDF_K_VARIANT"); return !(e && atoi(e) == 0); }();
+        if (k4)
+            hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), KCfg4::SMEM_BYTES, st, h->dW,
+                               (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
+        else
+            hipLaunchKernelGGL(k_exchange_K<KCfg>, dim3((unsigned)nblk), dim3(KCfg::NT), KCfg::SMEM_BYTES, st, h->dW,
+                               (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
         r.flops = 2.0 * (double)h->ntri * 128.0 * 128.0 * (double)h->S * (double)h->KS;
         r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
         r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
@@ -367,8 +381,10 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
     (void)hipEventCreate(&h->ev_end);
     (void)hipEventCreate(&h->ev_h2d);
     (void)hipEventCreate(&h->ev_d2h);
-    (void)hipFuncSetAttribute((const void *)k_exchange_K, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)k_exchange_K<KCfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               KCfg::SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void *)k_exchange_K<KCfg4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              KCfg4::SMEM_BYTES);
     (void)hipFuncSetAttribute((const void *)k_metric_apply, hipFuncAttributeMaxDynamicSharedMemorySize,
                               MCfg::SMEM_BYTES);
     *out = h;
@@ -434,11 +450,20 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     h->Nk = roundup(N, KC);
     h->Np = roundup(N, TILE_P);
     h->n_ntiles = (int)(h->Np / TILE_P);
-    // orbital (M) tiling of the W kernel: <= 128 orbitals per workgroup, balanced
-    h->n_mtiles = (int)((n_occ + 127) / 128);
-    h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
+    // orbital (M) tiling of the W kernel: up to 128 orbitals -> one 4-wave workgroup holds them all;
+    // more -> 8-wave workgroups of up to 256 orbitals (two wave rows share the staged B tile)
+    if (n_occ <= 128 || getenv("JCDF_W_NO_WVM2")) {
+        h->WVMw = 1;
+        h->n_mtiles = (int)((n_occ + 127) / 128);
+        h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
+    } else {
+        h->WVMw = 2;
+        h->n_mtiles = (int)((n_occ + 255) / 256);
+        h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 31) / 32);    // per wave row
+        if (h->WMw < 5) h->WMw = 5;
+    }
     h->rv = 0;
-    h->opad = h->n_mtiles * h->WMw * 16;
+    h->opad = h->n_mtiles * h->WVMw * h->WMw * 16;
     h->nvp = h->n_ntiles * h->n_mtiles;
     launch_W(h, nullptr, true);
     // K: lower block-triangle of 128x128 tiles, split-K so that one wave of workgroups fills the chip

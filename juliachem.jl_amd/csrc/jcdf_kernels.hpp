@@ -65,16 +65,19 @@ __global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int
 // MFMA row tiles and the 81st with VALU FMAs (1/6 fewer MFMAs) did not make it faster,
 // so n_occ is simply padded to a multiple of 16.
 // ---------------------------------------------------------------------------
-template <int WM>
-using WCfg = GemmCfg<WM, 2, 1, 4, KC>;
+// WVM = 1: 4 waves side by side, tile (16 WM) x 128.  WVM = 2 (more than 128 occupied
+// orbitals): 8 waves as 2 x 4, tile (32 WM) x 128 — the B tile is staged once for both
+// orbital halves instead of being re-read by a second workgroup.
+template <int WM, int WVM = 1>
+using WCfg = GemmCfg<WM, 2, WVM, 4, KC>;
 
-template <int WM, bool FUSE_V = true>
-__global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
+template <int WM, int WVM = 1, bool FUSE_V = true>
+__global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) ? 2 : 1)) void k_exchange_W(
     const double *__restrict__ B, const double *__restrict__ Cpad, const double *__restrict__ Cperm,
     double *__restrict__ W, double *__restrict__ vpart, int Ql, int o, int Nk, int Np, int opad,
     int n_mtiles, int n_ntiles, const int *__restrict__ kptr, const int *__restrict__ klist)
 {
-    using Cfg = WCfg<WM>;
+    using Cfg = WCfg<WM, WVM>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     // XCD-aware decode: blocks b and b+8 share an XCD/L2; keep the m-tiles that
@@ -92,11 +95,14 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
     for (int m = 0; m < WM; ++m) acc[m][0] = acc[m][1] = double4_t{0.0, 0.0, 0.0, 0.0};
 
     const double *Ag = Cpad + mt * Cfg::TM_MFMA;
+    const int emt = mt * WVM + (int)(threadIdx.x >> 6) / 4;           // 16*WM-row tile index of this wave (Cperm)
     const double *Bg = B + (int64_t)Q * Nk * Np + nt * Cfg::TN;
     // block sparsity: only the 16-row k stages in which this column tile has a kept (q,p) pair
     // (the Schwarz pattern does not depend on the aux index); dense map: all of them (kptr == null)
     const int k0 = kptr ? kptr[nt] : 0;
     const int nk = kptr ? kptr[nt + 1] - k0 : Nk / KC;
+    // 2-stage-deep register prefetch everywhere: for <7,2>/<8,2> the second register set costs a few
+    // dozen scratch spills but measured 3 % faster than the 1-deep variant on the (H2O)50 shape
     if (nk > 0) gemm_tn_core<Cfg, true, 0, 2>(Ag, opad, Bg, Np, nk, acc, smem, kptr ? klist + k0 : nullptr);
 
     double vsum = 0.0;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
         const int p = nt * Cfg::TN + tile_col<Cfg>(n);
         if (FUSE_V) {   // C[p][i] in accumulator layout: 2*WM coalesced 16-B loads (zero where i >= o)
             const double2_t *cp = reinterpret_cast<const double2_t *>(Cperm) +
-                                  ((int64_t)mt * (Np / 16) + (p >> 4)) * (2 * WM) * 64 + (threadIdx.x & 63);
+                                  ((int64_t)emt * (Np / 16) + (p >> 4)) * (2 * WM) * 64 + (threadIdx.x & 63);
 #pragma unroll
             for (int t = 0; t < 2 * WM; ++t) {
                 const double2_t c = cp[t * 64];
@@ -126,8 +132,11 @@ __global__ __launch_bounds__(256, (WM <= 6) ? 2 : 1) void k_exchange_W(
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off, 64);
     if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = vsum;   // all waves passed the core's last barrier
     __syncthreads();
-    if (threadIdx.x == 0)
-        vpart[(int64_t)Q * (n_ntiles * n_mtiles) + nt * n_mtiles + mt] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (threadIdx.x == 0) {
+        double sum = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+        if (WVM == 2) sum += (smem[4] + smem[5]) + (smem[6] + smem[7]);
+        vpart[(int64_t)Q * (n_ntiles * n_mtiles) + nt * n_mtiles + mt] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -212,12 +221,13 @@ __global__ __launch_bounds__(256) void k_coulomb_J(
 // k_fock_assemble.  Reference: calcululate_K_no_sym_GPU! / lower-triangle block
 // GEMMs (GPUDF.jl:669-672, 758-826) / DenseGPUDF.jl:111.
 // ---------------------------------------------------------------------------
-using KCfg = GemmCfg<4, 2, 2, 4, KC>;   // 128 x 128 tile, 8 waves of 64 x 32
+using KCfg = GemmCfg<4, 2, 2, 4, KC>;    // 128 x 128 tile, 8 waves of 64 x 32
+using KCfg4 = GemmCfg<4, 4, 2, 2, KC>;   // 128 x 128 tile, 4 waves of 64 x 64 (twice the MFMAs per barrier and per LDS read)
 
-__global__ __launch_bounds__(512) void k_exchange_K(
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, (Cfg::NT == 256) ? 2 : 1) void k_exchange_K(
     const double *__restrict__ W, int Np, int ntri, int S, int KS, double *__restrict__ Kslab)
 {
-    using Cfg = KCfg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // all tiles of one k-slice on one XCD: they re-read the same W rows through that L2
     const int b = blockIdx.x;

@@ -342,3 +342,22 @@ def test_operator_with_two_devices_in_one_process(monkeypatch):
     assert len(scf_data.gpu_data.handles) == 2 and tm.non_timing_data["contraction_algorithm"] == "screened hip"
     assert "GPU_2_W_time-1" in tm.timings and tm.non_timing_data["GPU_num_devices"] == "2"
     scf_data.gpu_data.close()
+
+
+@pytest.mark.parametrize("N,Q,o", [(300, 40, 129), (272, 36, 160), (260, 24, 250)])
+def test_fock_parity_more_than_128_occupied(N, Q, o):
+    """n_occ > 128 takes the 8-wave, two-wave-row W kernel (and n_occ = 250 is the (H2O)50 count)."""
+    s = synthetic.make(N, Q, o, seed=13)
+    B = orc.calculate_B(s.J2c, s.T)
+    Co = s.C[:, :o]
+    ref = s.H + orc.df_rhf_fock_build_BLAS(B, Co)
+    h = _handle(N, Q, 0, Q, o)
+    h.set_B(np.asfortranarray(B.reshape(Q, N * N, order="F")))
+    h.set_core_hamiltonian(s.H)
+    F, _ = h.fock_build(Co)
+    assert _rel(F, ref) < RTOL
+    _, V, _ = orc.calculate_coulomb_dense(B, Co)
+    assert _rel(h.get_V(), V) < RTOL
+    _, Wref = orc.calculate_exchange_dense(B, Co)
+    assert _rel(h.get_W(), Wref.transpose(1, 0, 2)) < RTOL
+    h.close()

@@ -157,10 +157,10 @@ int main(int argc, char **argv)
     {   // the product kernel itself (XCD decode, fused V epilogue)
         using Cfg = WCfg<6>;
         hipFuncSetAttribute((const void *)k_exchange_W<6>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
-        hipFuncSetAttribute((const void *)k_exchange_W<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
+        hipFuncSetAttribute((const void *)k_exchange_W<6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
         const int nnt = Np / Cfg::TN;
         const int nblk = ((Ql * nnt + 7) / 8) * 8;
-        vs.push_back({"PRODUCT k_exchange_W<6> without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, false>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
+        vs.push_back({"PRODUCT k_exchange_W<6> without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, 1, false>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
         vs.push_back({"PRODUCT k_exchange_W<6>", [=] { hipLaunchKernelGGL((k_exchange_W<6>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
     }
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
