@@ -774,7 +774,7 @@ static int sytrd_groups(int64_t n, size_t *lds_bytes)
     }
     if (env) {
         const int want = atoi(env);
-        if (want >= G && want <= 256) {
+        if (want >= 1 && want <= 256 && (size_t)(((n + want - 1) / want) * n + 2 * n + 16) * 8 <= 160 * 1024) {
             G = want;
             *lds_bytes = (size_t)(((n + G - 1) / G) * n + 2 * n + 16) * 8;
         }

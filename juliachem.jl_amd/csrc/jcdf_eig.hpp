@@ -47,7 +47,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned long long *bar, unsigned l
         __hip_atomic_fetch_add(bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = wall_clock64();                       // 100 MHz
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 5000000ULL) {                         // 50 ms: a peer is gone
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
@@ -208,11 +208,14 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
                 reflector(k + 1);
                 cfirst = c0 + 1;
             }
-            const int ncu = nc - cfirst;
-            for (int idx = tid; idx < ncu * m; idx += nthr) {
-                const int c = cfirst + idx / m, i = idx % m;
-                const int jj = g + c * G - (k + 1);
-                slab[(size_t)c * n + (k + 1) + i] -= vs[i] * ws[jj] + ws[i] * vs[jj];
+            {   // one wave per column, lanes along the rows (no integer division in the hot loop)
+                const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+                for (int c = cfirst + wave; c < nc; c += nw) {
+                    const int jj = g + c * G - (k + 1);
+                    const double wj = ws[jj], vj = vs[jj];
+                    double *col = slab + (size_t)c * n + (k + 1);
+                    for (int i = lane; i < m; i += 64) col[i] -= vs[i] * wj + ws[i] * vj;
+                }
             }
         } else if (next_owner) {
             reflector(k + 1);
