@@ -785,7 +785,8 @@ static int sytrd_groups(int64_t n, size_t *lds_bytes)
 int64_t jcdf_sytrd_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    return 64 + (int64_t)(4 * n + 2 * 256 + 2) * 8;
+    // err word (64 B header) + granule pairs: v 2(n+1), y 2n, dots 2*256; 16 B per pair
+    return 64 + (int64_t)(2 * (n + 1) + 2 * n + 2 * 256) * 16;
 }
 
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
@@ -798,14 +799,13 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
     if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // n too large for LDS residency (n <~ 2200)
     hipStream_t st = (hipStream_t)stream;
     char *w = (char *)d_work;
-    unsigned long long *bar = (unsigned long long *)w;
     int *err = (int *)(w + 8);
-    unsigned long long *vflag = (unsigned long long *)(w + 16);
-    double *vbuf = (double *)(w + 64), *ybuf = vbuf + 2 * n, *dots = ybuf + 2 * n;
-    if (hipMemsetAsync(w, 0, 64, st) != hipSuccess) return JCDF_ERR_HIP;
+    jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 4 * (n + 1), *dg = yg + 4 * n;
+    // tags restart at 1 every call: all granules (and the error word) are zeroed first
+    if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
     (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vbuf,
-                       ybuf, dots, bar, vflag, err);
+    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
+                       dg, err);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

@@ -7,14 +7,13 @@
 // is LAPACK dsytd2 (unblocked, 'L'): N-2 dependent steps, each a symv and a rank-2 update of
 // the trailing matrix — only ~2.7e8 flops in total at N = 510, pure latency.  Here the matrix
 // lives in LDS, distributed column-cyclically over G workgroups (G <= #CUs, one per CU, all
-// co-resident), and the N-2 steps run inside one launch with two grid barriers per step.
+// co-resident), and the N-2 steps run inside one launch.
 //
-// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH "Valid
-// forms", table row 1): every handed-off double is written with an agent-scope relaxed
-// atomic store (sc1, write-through) and read with an agent-scope relaxed atomic load (sc1,
-// bypasses L1); each storing wave drains with s_waitcnt vmcnt(0), the workgroup barriers, one
-// lane adds to a monotonic agent-scope counter and polls it; the other waves continue after a
-// workgroup barrier.  Every spin is bounded by a wall-clock timeout that raises an error word.
+// Inter-workgroup hand-off: tagged 8-byte granules (see below) — no grid barrier, no fence; every
+// spin is bounded by a wall-clock timeout that raises an error word.  Per column two all-to-all
+// exchanges remain (the reflector v, then y = tau A v): ~7 us per column on MI355X, which is the
+// fabric's all-gather latency (MI355X_MICROARCH price list: 8 KB all-gather ~2.4-3 us), not
+// arithmetic.  A first version with two counter grid barriers per column measured the same 7.5 us.
 //
 // Output is LAPACK-compatible (dsytrd 'L'): D, E, TAU and the Householder vectors below the
 // sub-diagonal of A, so rocSOLVER's stedc + ormtr finish the eigendecomposition.
@@ -24,41 +23,84 @@
 
 namespace jcdf {
 
-__device__ __forceinline__ void st_sc1(double *p, double v)
+// ---- tagged hand-off granules -----------------------------------------------------------
+// A handed-off double travels as two naturally aligned 8-byte words {tag32, half32}, each written
+// by ONE agent-scope relaxed atomic store (sc1, write-through) and read by agent-scope relaxed
+// atomic loads (sc1, bypass L1): "the data IS the flag" (cdna_hip_programming.md Guideline 16,
+// recipe R2: 8-byte {tag, value} granules need no flag, no fence and no ordering).  The tag is
+// the step number, so a consumer simply re-reads until both tags match; stale contents of the
+// reused buffers can never be mistaken for fresh data.  This removes every grid barrier from the
+// tridiagonalisation: per column there are two store->load hops (v, then y) instead of six.
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void pub(u64 *g, int idx, double v, unsigned tag)
 {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_sc1(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(
-        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const u64 bits = (u64)__double_as_longlong(v);
+    __hip_atomic_store(g + 2 * idx, ((u64)tag << 32) | (bits & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 2 * idx + 1, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Monotonic-counter grid barrier.  Returns false on timeout (error word set).
-// `flag` is one double of the kernel's dynamic LDS (no static __shared__: it would shift the
-// dynamic base off its 16-B alignment, Guideline 17).
-__device__ __forceinline__ bool grid_barrier(unsigned long long *bar, unsigned long long target, int *err, double *flag)
+// Returns false on timeout / peer failure (error word set).
+__device__ __forceinline__ bool sub(const u64 *g, int idx, unsigned tag, double *out, int *err)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its sc1 stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        __hip_atomic_fetch_add(bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();                       // 100 MHz
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 5000000ULL) {                         // 50 ms: a peer is gone
+    u64 a, b;
+    unsigned spins = 0;
+    u64 t0 = 0;
+    for (;;) {
+        a = __hip_atomic_load(g + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(g + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) break;
+        if (++spins == 64) t0 = wall_clock64();
+        if (spins > 64 && (spins & 63) == 0) {
+            if (wall_clock64() - t0 > 5000000ULL) {                              // 50 ms at 100 MHz
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
+                return false;
             }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         }
-        *flag = ok ? 1.0 : 0.0;
+        __builtin_amdgcn_s_sleep(1);
     }
-    __syncthreads();
-    return *flag != 0.0;
+    *out = __longlong_as_double((long long)(((b & 0xffffffffULL) << 32) | (a & 0xffffffffULL)));
+    return true;
+}
+
+// Batched form: elements idx = first + e*stride (e < 8, idx < count) are requested together, so a
+// thread pays one memory round trip for all of them instead of one per element.
+__device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int count, unsigned tag, double *dst, int *err)
+{
+    unsigned pending = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (first + e * stride < count) pending |= 1u << e;
+    unsigned spins = 0;
+    u64 t0 = 0;
+    while (pending) {
+        u64 a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (pending & (1u << e)) {
+                const int idx = first + e * stride;
+                a[e] = __hip_atomic_load(g + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[e] = __hip_atomic_load(g + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((pending & (1u << e)) && (unsigned)(a[e] >> 32) == tag && (unsigned)(b[e] >> 32) == tag) {
+                dst[first + e * stride] = __longlong_as_double((long long)(((b[e] & 0xffffffffULL) << 32) | (a[e] & 0xffffffffULL)));
+                pending &= ~(1u << e);
+            }
+        if (!pending) break;
+        if (++spins == 64) t0 = wall_clock64();
+        if (spins > 64 && (spins & 63) == 0) {
+            if (wall_clock64() - t0 > 5000000ULL) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
 }
 
 __device__ __forceinline__ double block_sum(double x, double *red)
@@ -73,40 +115,25 @@ __device__ __forceinline__ double block_sum(double x, double *red)
     return s;
 }
 
-// Wait until the agent-scope word *flag reaches `want` (one lane polls, bounded).
-__device__ __forceinline__ bool flag_wait(const unsigned long long *flag, unsigned long long want, int *err, double *lflag)
+// true iff every thread of the workgroup passes `ok`
+__device__ __forceinline__ bool block_all(bool ok, double *red)
 {
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 5000000ULL) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-        }
-        *lflag = ok ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    return *lflag != 0.0;
+    return block_sum(ok ? 0.0 : 1.0, red) == 0.0;
 }
 
-// A: n x n symmetric (full storage, lda >= n).  Workspace (device; the 64-byte header holding
-// `bar`, `err`, `vflag[2]` is zeroed before launch):
-//   vbuf, ybuf: 2*n doubles each (slot n-1 of a vbuf half carries tau); dots: 2*gridDim.x doubles.
+// A: n x n symmetric (full storage, lda >= n).  Workspace: `err` word + granule buffers
+//   vg: 2 x (n+1) granule pairs (slot n of a half carries tau), yg: 2 x n, dg: 2 x gridDim.x,
+// all zeroed before launch (tags start at 1).
 // LDS: (ncol_max * n + 2 n + 16) doubles, ncol_max = ceil(n / gridDim.x).
 //
-// Per step k: [owner of column k has published its reflector v_k (flag)] -> everyone: y = tau A22 v
-// for its own columns -> ONE grid barrier -> everyone: w, rank-2 update of its own columns; the
-// owner of column k+1 updates that column FIRST, builds and publishes v_{k+1}, and only then
-// updates the rest, so the next step's reflector is in flight while the others still update.
+// Per column k:  owner publishes v_k, tau_k  ->  everyone: y = tau A22 v for its own columns,
+// publishes y and its partial v.y  ->  everyone: w, rank-2 update of its own columns; the owner of
+// column k+1 updates that column FIRST and publishes v_{k+1} before it updates the rest.
+// Buffer reuse (parity of k) is safe without barriers: v_{k+2} can only be formed after every
+// workgroup has published y_{k+1}, i.e. after it has consumed v_{k+1}, v_k and y_k.
 __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     double *vbuf, double *ybuf, double *dots,
-                                                     unsigned long long *bar, unsigned long long *vflag, int *err)
+                                                     u64 *vg, u64 *yg, u64 *dg, int *err)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -115,8 +142,7 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     double *slab = lds;                                   // column c (global j = g + c G) at slab + c*n
     double *vs = lds + (size_t)ncol_max * n;
     double *ws = vs + n;
-    double *red = ws + n;                                 // 8 doubles for reductions + 1 barrier flag
-    double *bflag = red + 8;
+    double *red = ws + n;                                 // 8 doubles for reductions
 
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) slab[(size_t)c * n + i] = A[(size_t)(g + c * G) * lda + i];
@@ -125,7 +151,8 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     // dlarfg on x = A[k+1:n, k] (column k is local column k / G of its owner); publishes v_k, tau_k
     auto reflector = [&](int k) {
         const int m = n - k - 1, buf = k & 1;
-        double *vb = vbuf + (size_t)buf * n;
+        const unsigned tag = (unsigned)(k + 1);
+        u64 *vb = vg + (size_t)buf * 2 * (n + 1);
         double *x = slab + (size_t)(k / G) * n + (k + 1);
         double part = 0.0;
         for (int i = 1 + tid; i < m; i += nthr) part += x[i] * x[i];
@@ -138,42 +165,41 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             scale = 1.0 / (alpha - beta);
         }
         __syncthreads();
+        if (tid == 0) pub(vb, n, tau, tag);
         for (int i = tid; i < m; i += nthr) {
             const double v = (i == 0) ? 1.0 : x[i] * scale;
-            st_sc1(vb + i, v);
+            pub(vb, i, v, tag);
             if (i > 0) x[i] = v;                          // LAPACK storage of the reflector
         }
         if (tid == 0) {
             x[0] = beta;                                  // E[k] lives on the sub-diagonal
-            st_sc1(vb + (n - 1), tau);
             E[k] = beta;
             TAU[k] = tau;
             D[k] = slab[(size_t)(k / G) * n + k];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains, then ONE lane flags
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(vflag + buf, (unsigned long long)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     if (n > 1 && g == 0) reflector(0);
-    unsigned long long phase = 0;
     for (int k = 0; k < n - 1; ++k) {
         const int m = n - k - 1;                          // rows k+1 .. n-1
         const int buf = k & 1;
-        const double *vb = vbuf + (size_t)buf * n;
-        double *yb = ybuf + (size_t)buf * n;
-        if (!flag_wait(vflag + buf, (unsigned long long)(k + 1), err, bflag)) return;
+        const unsigned tag = (unsigned)(k + 1);
+        const u64 *vb = vg + (size_t)buf * 2 * (n + 1);
+        u64 *yb = yg + (size_t)buf * 2 * n;
+        u64 *db = dg + (size_t)buf * 2 * G;
 
-        // ---- everyone: v, tau -> LDS; y_j = tau * A22[:, j] . v for my columns j > k
-        for (int i = tid; i < m; i += nthr) vs[i] = ld_sc1(vb + i);
-        if (tid == 0) vs[n - 1] = ld_sc1(vb + (n - 1));
-        __syncthreads();
+        // ---- everyone: v, tau -> LDS (each thread waits for its own elements)
+        bool ok = true;
+        for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(vb, i0, nthr, m, tag, vs, err);
+        if (tid == 0 && ok) ok = sub(vb, n, tag, vs + (n - 1), err);
+        if (!block_all(ok, red)) return;
         const double tau = vs[n - 1];
         const int c0 = (k + 1 - g + G - 1) / G;           // first local column with j > k
+        const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+
+        // ---- y_j = tau * A22[:, j] . v for my columns j > k ; partial v.y
         double dpart = 0.0;
         if (tau != 0.0) {
-            const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
             for (int c = c0 + wave; c < nc; c += nw) {
                 const double *col = slab + (size_t)c * n + (k + 1);
                 double s = 0.0;
@@ -183,22 +209,27 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
                 if (lane == 0) {
                     const int j = g + c * G;
                     const double y = tau * s;
-                    st_sc1(yb + (j - (k + 1)), y);
+                    pub(yb, j - (k + 1), y, tag);
                     dpart += vs[j - (k + 1)] * y;
                 }
             }
+            dpart = block_sum(dpart, red);                // lane 0 of each wave carried its partial
+            if (tid == 0) pub(db, g, dpart, tag);
         }
-        dpart = block_sum(dpart, red);                    // lane 0 of each wave carried its partial
-        if (tid == 0) st_sc1(dots + (size_t)buf * G + g, dpart);
-        if (!grid_barrier(bar, (++phase) * (unsigned long long)G, err, bflag)) return;
 
         // ---- everyone: w = y - (tau/2)(y.v) v ; A22[:, j] -= v w_j + w v_j for my columns j > k
         const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
         if (tau != 0.0) {
             double dl = 0.0;
-            for (int q = tid; q < G; q += nthr) dl += ld_sc1(dots + (size_t)buf * G + q);
+            for (int q = tid; q < G && ok; q += nthr) {
+                double dq;
+                ok = sub(db, q, tag, &dq, err);
+                dl += dq;
+            }
+            for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(yb, i0, nthr, m, tag, ws, err);   // ws = y for now
+            if (!block_all(ok, red)) return;
             const double al = -0.5 * tau * block_sum(dl, red);
-            for (int i = tid; i < m; i += nthr) ws[i] = ld_sc1(yb + i) + al * vs[i];
+            for (int i = tid; i < m; i += nthr) ws[i] += al * vs[i];
             __syncthreads();
             int cfirst = c0;
             if (next_owner) {                             // column k+1 first, then its reflector goes out
@@ -208,14 +239,11 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
                 reflector(k + 1);
                 cfirst = c0 + 1;
             }
-            {   // one wave per column, lanes along the rows (no integer division in the hot loop)
-                const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-                for (int c = cfirst + wave; c < nc; c += nw) {
-                    const int jj = g + c * G - (k + 1);
-                    const double wj = ws[jj], vj = vs[jj];
-                    double *col = slab + (size_t)c * n + (k + 1);
-                    for (int i = lane; i < m; i += 64) col[i] -= vs[i] * wj + ws[i] * vj;
-                }
+            for (int c = cfirst + wave; c < nc; c += nw) {              // one wave per column, lanes along the rows
+                const int jj = g + c * G - (k + 1);
+                const double wj = ws[jj], vj = vs[jj];
+                double *col = slab + (size_t)c * n + (k + 1);
+                for (int i = lane; i < m; i += 64) col[i] -= vs[i] * wj + ws[i] * vj;
             }
         } else if (next_owner) {
             reflector(k + 1);
