@@ -446,8 +446,26 @@ class JCDFHandle:
                      alg_flops=arr[i].alg_flops, alg_bytes=arr[i].alg_bytes) for i in range(n)]
 
 
+def lapack_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
+    """L^-1 exactly as the reference forms it on the host: LAPACK.potrf!('L') + trtri!('L','N')
+    (GPUDF.jl:890-891, DensityFitting.jl:137-140), through scipy's LAPACK.  Upper triangle zeroed
+    (TwoCenterIntegrals.jl:150-162).  Falls back to the library's own host routine without scipy."""
+    try:
+        from scipy.linalg import lapack
+    except Exception:
+        return host_potrf_trtri(J2c)
+    a = np.array(J2c, dtype=np.float64, order="F", copy=True)
+    c, info = lapack.dpotrf(a, lower=1, overwrite_a=1)
+    if info != 0:
+        raise JCDFError(5, "metric not positive definite at pivot %d" % info)
+    inv, info = lapack.dtrtri(c, lower=1, overwrite_c=1)
+    if info != 0:
+        raise JCDFError(5, "dtrtri info=%d" % info)
+    return np.asfortranarray(np.tril(inv))
+
+
 def host_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
-    """L^-1 via the library's host Cholesky/inverse (GPUDF.jl:890-891)."""
+    """L^-1 via the library's dependency-free host Cholesky/inverse (what jcdf_set_metric runs)."""
     a = np.array(J2c, dtype=np.float64, order="F", copy=True)
     rc = _lib.load().jcdf_host_potrf_trtri(a.ctypes.data, a.shape[0])
     if rc != 0:
@@ -529,7 +547,7 @@ def calculate_B_GPU(scf_data: SCFData, engine: DFIntegralEngine, two_center_inte
     gd.device_Q_indices = ranges
     gd.device_Q_range_lengths = [len(r) for r in ranges]
     t0 = time.perf_counter()
-    Linv = host_potrf_trtri(two_center_integrals)
+    Linv = lapack_potrf_trtri(two_center_integrals)
     jc_timing.timings[JCTC.form_J_AB_inv_time] = time.perf_counter() - t0
     for h in gd.handles:
         h.set_metric_inverse(Linv)

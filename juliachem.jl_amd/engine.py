@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .df import JCDFHandle, host_potrf_trtri
+from .df import JCDFHandle, lapack_potrf_trtri
 from .eigh import DeviceEigh
 
 
@@ -118,7 +118,7 @@ class DeviceFockBuilder:
 
     # ---- setup -----------------------------------------------------------------
     def set_metric(self, J2c: np.ndarray) -> None:
-        self.h.set_metric_inverse(host_potrf_trtri(J2c))     # potrf/trtri on the host, GPUDF.jl:890-891
+        self.h.set_metric_inverse(lapack_potrf_trtri(J2c))   # LAPACK potrf/trtri on the host, GPUDF.jl:890-891
 
     def set_core_hamiltonian(self, H: np.ndarray) -> None:
         self.h.set_core_hamiltonian(H if self.rank == 0 else None)     # GPUDF.jl:158-161
