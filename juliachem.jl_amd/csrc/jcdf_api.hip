@@ -42,7 +42,7 @@ struct jcdf_handle {
     // sizes
     int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
     int64_t Nk = 0, Np = 0;
-    int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0, rv = 0;
+    int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0;
     int ntri = 0, S = 0, KS = 0;
     int SJ = 0, QS = 0;
     int64_t Wrows = 0;
@@ -462,7 +462,6 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 31) / 32);    // per wave row
         if (h->WMw < 5) h->WMw = 5;
     }
-    h->rv = 0;
     h->opad = h->n_mtiles * h->WVMw * h->WMw * 16;
     h->nvp = h->n_ntiles * h->n_mtiles;
     launch_W(h, nullptr, true);
