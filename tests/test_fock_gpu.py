@@ -361,3 +361,20 @@ def test_fock_parity_more_than_128_occupied(N, Q, o):
     _, Wref = orc.calculate_exchange_dense(B, Co)
     assert _rel(h.get_W(), Wref.transpose(1, 0, 2)) < RTOL
     h.close()
+
+
+@pytest.mark.parametrize("N,Q,o", [(1, 1, 1), (2, 3, 2), (5, 1, 5), (16, 2, 16), (129, 3, 1)])
+def test_degenerate_sizes(N, Q, o):
+    """Smallest possible problems: one AO, one aux function, all orbitals occupied, a single
+    occupied orbital next to a column-tile edge."""
+    s = synthetic.make(N, Q, o, seed=3)
+    B = orc.calculate_B(s.J2c, s.T)
+    Co = s.C[:, :o]
+    h = _handle(N, Q, 0, Q, o)
+    h.set_metric(np.tril(s.J2c))
+    h.push_three_center(0, Q, np.asfortranarray(s.T.reshape(Q, N * N, order="F")))
+    h.set_core_hamiltonian(s.H)
+    F, _ = h.fock_build(Co)
+    ref = s.H + orc.df_rhf_fock_build_BLAS(B, Co)
+    assert _rel(F, ref) < RTOL
+    h.close()
