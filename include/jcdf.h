@@ -107,10 +107,13 @@ int32_t jcdf_abi_version(void);
 int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, int64_t q1,
                        int64_t n_occ, int64_t P, const int64_t *pq_p, const int64_t *pq_q);
 
-/* Metric.  `J2c` = two_center_integrals (Q_total x Q_total, lower triangle
- * valid, TwoCenterIntegrals.jl:7-29).  Performs potrf('L') + trtri('L','N')
- * on the host (GPUDF.jl:890-891, DensityFitting.jl:137-140) and uploads the
- * rows [q0,q1) of L^-1. */
+/* Metric.  `J2c` = two_center_integrals (Q_total x Q_total column-major, only the
+ * lower triangle is read, TwoCenterIntegrals.jl:7-29).  Performs potrf('L') +
+ * trtri('L','N') ON THE DEVICE (blocked fp64-MFMA factorisation, csrc/jcdf_chol.hpp —
+ * the placement of CUSOLVER.potrf!/trtri! at DenseGPUDF.jl:185-193; the screened
+ * path does it with host LAPACK at GPUDF.jl:890-891) and keeps rows [q0,q1) of
+ * L^-1.  JCDF_ERR_NOT_SPD on a non-positive pivot.  Environment JCDF_HOST_CHOLESKY=1
+ * selects the library's host potrf/trtri instead (debug). */
 int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c);
 /* Same, when the caller already holds L^-1 (Q_total x Q_total, lower
  * triangular, upper = 0) — what GPUDF.jl:893-902 uploads / broadcasts. */
@@ -168,6 +171,11 @@ int32_t jcdf_get_W(jcdf_handle *h, double *W_out);
  * A (LAPACK.potrf!('L') + trtri!('L','N'), GPUDF.jl:890-891).  Returns 0, or the
  * 1-based index of the first non-positive pivot.  Upper triangle is zeroed. */
 int32_t jcdf_host_potrf_trtri(double *A, int64_t n);
+/* The device factorisation jcdf_set_metric runs, exported with the same contract for
+ * parity tests: A (host, n x n column-major, lower triangle read) is overwritten with
+ * L^-1 (lower triangular, upper = 0).  Returns a jcdf_status (JCDF_ERR_NOT_SPD on a
+ * non-positive pivot). */
+int32_t jcdf_device_potrf_trtri(int32_t device_id, double *A, int64_t n);
 
 /* Caller-side helper for the replicated eigensolve of the SCF iteration (reference: host
  * LAPACK eigen!(Hermitian(.)) at src/rhf/energy/SCF.jl:1083): Householder tridiagonalisation

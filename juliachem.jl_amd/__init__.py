@@ -11,7 +11,7 @@ from .df import (JCDFHandle, JCTC, JCTiming, JCTiming_GPUkey, JCTiming_key, SCFD
                  SCFOptions, ScreeningData, Basis, Shell, CalculationBasisSets, DFIntegralEngine,
                  TensorIntegralEngine, basis_from_shell_sizes, create_jctiming, create_scf_options,
                  df_rhf_fock_build, df_rhf_fock_build_GPU, get_default_gpu_data_hip,
-                 get_screening_metadata, host_potrf_trtri, lapack_potrf_trtri, packed_pq_lists,
+                 get_screening_metadata, host_potrf_trtri, device_potrf_trtri, lapack_potrf_trtri, packed_pq_lists,
                  setup_unscreened_screening_matricies, static_load_rank_indicies,
                  calculate_device_ranges_GPU)
 

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "jcdf_get_V": (C.c_int32, [_P, _P]),
     "jcdf_get_W": (C.c_int32, [_P, _P]),
     "jcdf_host_potrf_trtri": (C.c_int32, [_P, _I64]),
+    "jcdf_device_potrf_trtri": (C.c_int32, [C.c_int32, _P, _I64]),
     "jcdf_sytrd_workspace_bytes": (_I64, [_I64]),
     "jcdf_sytrd_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
     "jcdf_device_bytes": (_I64, [_P]),

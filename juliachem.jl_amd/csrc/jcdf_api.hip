@@ -7,6 +7,7 @@
 #include "jcdf_kernels.hpp"
 #include "jcdf_host_lapack.hpp"
 #include "jcdf_eig.hpp"
+#include "jcdf_chol.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -171,7 +172,7 @@ void launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 
 KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t st)
 {
-    if (h->recs.size() <= idx) {
+    while (h->recs.size() <= idx) {
         KernelRec r{};
         (void)hipEventCreate(&r.e0);
         (void)hipEventCreate(&r.e1);
@@ -205,17 +206,17 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
         (void)hipEventRecord(r.e1, st);
     }
-    {
-        KernelRec &r = rec_begin(h, k++, "k_coulomb_J", st);
+    auto run_J = [&](size_t slot) {
+        KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st);
         hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)((h->N + J_ROWS - 1) / J_ROWS), (unsigned)h->SJ), dim3(256),
                            (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
                            (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV, h->dJmask);
         r.flops = r.alg_flops = Ql * N * (N + 1.0);
         r.alg_bytes = 8.0 * Ql * N * (N + 1.0) / 2.0;               // lower triangle of B, once
         (void)hipEventRecord(r.e1, st);
-    }
-    {
-        KernelRec &r = rec_begin(h, k++, "k_exchange_K", st);
+    };
+    auto run_K = [&](size_t slot) {
+        KernelRec &r = rec_begin(h, slot, "k_exchange_K", st);
         const int nblk = (int)(roundup(h->S, 8) * h->ntri);
         static const bool k4 = [] { const char *e = getenv("JCDF_K_VARIANT"); return !(e && atoi(e) == 0); }();
         if (k4)
@@ -228,7 +229,11 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
         r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
         (void)hipEventRecord(r.e1, st);
-    }
+    };
+    // record slots stay fixed (2 = J, 3 = K) whatever the launch order
+    static const bool k_first = [] { const char *e = getenv("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
+    if (k_first) { run_K(3); run_J(2); } else { run_J(2); run_K(3); }
+    k = 4;
     {
         KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st);
         hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
@@ -314,6 +319,84 @@ int32_t push_block(jcdf_handle *h, int64_t s0, int64_t s1, const double *T, bool
     return JCDF_OK;
 }
 
+// ---- device Cholesky + triangular inverse of the metric (jcdf_chol.hpp) ------------------------
+struct CholBuffers {
+    double *R = nullptr, *V = nullptr, *invU = nullptr, *UT = nullptr, *T = nullptr;
+    int *err = nullptr;
+    int64_t n_pad = 0, ld = 0, nblk = 0;
+    ~CholBuffers()
+    {
+        (void)hipFree(R); (void)hipFree(V); (void)hipFree(invU); (void)hipFree(UT); (void)hipFree(T); (void)hipFree(err);
+    }
+};
+
+// Factor the Q x Q SPD matrix whose column-major lower triangle is at host pointer J and leave
+// V = (L^-1)^T (row-major upper, leading dimension w.ld) in w.V.  *info = 0 or the 1-based index
+// of the first non-positive pivot.  Everything runs on `st`; returns after a stream sync.
+hipError_t chol_inverse_device(hipStream_t st, const double *J, int64_t Q, CholBuffers &w, int *info)
+{
+#define CH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+    w.n_pad = roundup(Q, 128);
+    w.ld = w.n_pad + CH_NB;
+    w.nblk = w.n_pad / CH_NB;
+    const size_t mat = (size_t)(w.ld * w.ld) * 8;
+    CH(hipMalloc((void **)&w.R, mat));
+    CH(hipMalloc((void **)&w.V, mat));
+    CH(hipMalloc((void **)&w.invU, (size_t)w.nblk * CH_NB * CH_NB * 8));
+    CH(hipMalloc((void **)&w.UT, (size_t)w.ld * CH_NB * 8));
+    CH(hipMalloc((void **)&w.T, (size_t)w.ld * CH_NB * 8));
+    CH(hipMalloc((void **)&w.err, 64));
+    CH(hipMemsetAsync(w.R, 0, mat, st));
+    CH(hipMemsetAsync(w.V, 0, mat, st));
+    CH(hipMemsetAsync(w.UT, 0, (size_t)w.ld * CH_NB * 8, st));
+    CH(hipMemsetAsync(w.T, 0, (size_t)w.ld * CH_NB * 8, st));
+    CH(hipMemsetAsync(w.err, 0, 64, st));
+    CH(hipMemcpy2DAsync(w.R, (size_t)w.ld * 8, J, (size_t)Q * 8, (size_t)Q * 8, (size_t)Q, hipMemcpyHostToDevice, st));
+    if (w.n_pad > Q)
+        hipLaunchKernelGGL(k_chol_pad_diag, dim3((unsigned)((w.n_pad - Q + 127) / 128)), dim3(128), 0, st, w.R, w.ld,
+                           (int)Q, (int)w.n_pad);
+    const int diag_lds = 2 * CH_NB * (CH_NB + 1) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds);
+        (void)hipFuncSetAttribute((const void *)k_chol_inv_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, C64Cfg::SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_chol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, C128Cfg::SMEM_BYTES);
+        attr_done = true;
+    }
+    // factor: R -> U (upper, row-major)
+    for (int64_t b = 0; b < w.nblk; ++b) {
+        const int64_t i0 = b * CH_NB, k0 = i0 + CH_NB, nk = w.n_pad - k0;
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), diag_lds, st, w.R, w.ld, (int)i0,
+                           w.invU + b * CH_NB * CH_NB, w.err);
+        if (nk <= 0) continue;
+        const unsigned nt = (unsigned)((nk + 127) / 128);
+        double *R12 = w.R + i0 * w.ld + k0;
+        hipLaunchKernelGGL(k_chol_trsm<true>, dim3((unsigned)(nk / 64)), dim3(64), 0, st, w.R + i0 * w.ld + i0, w.ld,
+                           R12, w.ld, R12, w.ld, nk);
+        hipLaunchKernelGGL(k_chol_syrk, dim3(nt * (nt + 1) / 2), dim3(C128Cfg::NT), C128Cfg::SMEM_BYTES, st, R12,
+                           w.R + k0 * w.ld + k0, w.ld, (int)nt);
+    }
+    // inverse: V = U^-1, block rows bottom-up
+    for (int64_t b = w.nblk - 1; b >= 0; --b) {
+        const int64_t i0 = b * CH_NB, k0 = i0 + CH_NB, nk = w.n_pad - k0;
+        hipLaunchKernelGGL(k_chol_put_diag, dim3(CH_NB * CH_NB / 256), dim3(256), 0, st, w.invU + b * CH_NB * CH_NB,
+                           w.V, w.ld, (int)i0);
+        if (nk <= 0) continue;
+        const unsigned nt = (unsigned)((nk + 127) / 128);
+        hipLaunchKernelGGL(k_chol_transpose_panel, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, st, w.R, w.ld,
+                           (int)i0, k0, nk, w.UT);
+        hipLaunchKernelGGL(k_chol_inv_gemm, dim3(nt), dim3(C64Cfg::NT), C64Cfg::SMEM_BYTES, st, w.UT, w.V, w.ld, k0,
+                           w.T, w.ld);
+        hipLaunchKernelGGL(k_chol_trsm<false>, dim3((unsigned)(nk / 64)), dim3(64), 0, st, w.R + i0 * w.ld + i0, w.ld,
+                           w.T, w.ld, w.V + i0 * w.ld + k0, w.ld, nk);
+    }
+    CH(hipGetLastError());
+    CH(hipMemcpyAsync(info, w.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    CH(hipStreamSynchronize(st));
+#undef CH
+    return hipSuccess;
+}
+
 int32_t upload_linv(jcdf_handle *h, const double *Linv)
 {
     // LinvT[s][r] = Linv[(q0 + r) + Qtot * s]: column s of Linv restricted to the shard's rows
@@ -327,6 +410,25 @@ int32_t upload_linv(jcdf_handle *h, const double *Linv)
     }
     JCDF_HIP(h, hipMemcpy2DAsync(h->dLinvT, (size_t)h->ldl * 8, Linv + h->q0, (size_t)h->Qtot * 8,
                                  (size_t)h->Ql * 8, (size_t)h->Qtot, hipMemcpyHostToDevice, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_metric = true;
+    return JCDF_OK;
+}
+
+
+// LinvT[s][r] = V[s][q0 + r] straight from the device factorisation
+int32_t upload_linv_from_device(jcdf_handle *h, const CholBuffers &w)
+{
+    h->ldl = roundup(h->Ql, MCfg::TM);
+    h->linv_rows = h->Qtot + 2 * KC;
+    if (!h->dLinvT) {
+        int32_t rc = dev_alloc(h, &h->dLinvT, h->linv_rows * h->ldl, true);
+        if (rc) return rc;
+    } else {
+        JCDF_HIP(h, hipMemsetAsync(h->dLinvT, 0, (size_t)(h->linv_rows * h->ldl) * 8, h->stream));
+    }
+    JCDF_HIP(h, hipMemcpy2DAsync(h->dLinvT, (size_t)h->ldl * 8, w.V + h->q0, (size_t)w.ld * 8, (size_t)h->Ql * 8,
+                                 (size_t)h->Qtot, hipMemcpyDeviceToDevice, h->stream));
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_metric = true;
     return JCDF_OK;
@@ -553,16 +655,43 @@ int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c)
     if (!h) return JCDF_ERR_INVALID;
     if (!h->configured || !J2c) return fail(h, JCDF_ERR_INVALID, "jcdf_set_metric: configure first / NULL");
     JCDF_HIP(h, hipSetDevice(h->device));
-    std::vector<double> L;
-    try {
-        L.assign(J2c, J2c + (size_t)(h->Qtot * h->Qtot));
-    } catch (...) {
-        return fail(h, JCDF_ERR_ALLOC, "jcdf_set_metric: out of host memory");
+    if (getenv("JCDF_HOST_CHOLESKY")) {              // host potrf/trtri (the reference's GPUDF.jl:890-891 placement)
+        std::vector<double> L;
+        try {
+            L.assign(J2c, J2c + (size_t)(h->Qtot * h->Qtot));
+        } catch (...) {
+            return fail(h, JCDF_ERR_ALLOC, "jcdf_set_metric: out of host memory");
+        }
+        const int info = hostlapack::potrf_trtri_lower(L.data(), h->Qtot);
+        if (info != 0)
+            return fail(h, JCDF_ERR_NOT_SPD, "jcdf_set_metric: (P|Q) not positive definite at pivot " + std::to_string(info));
+        return upload_linv(h, L.data());
     }
-    const int info = hostlapack::potrf_trtri_lower(L.data(), h->Qtot);
+    CholBuffers w;                                   // device potrf/trtri (DenseGPUDF.jl:185-193 placement)
+    int info = 0;
+    hipError_t e = chol_inverse_device(h->stream, J2c, h->Qtot, w, &info);
+    if (e == hipErrorOutOfMemory) return fail(h, JCDF_ERR_ALLOC, "jcdf_set_metric: out of device memory for the factorisation");
+    if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("jcdf_set_metric: ") + hipGetErrorString(e));
     if (info != 0)
         return fail(h, JCDF_ERR_NOT_SPD, "jcdf_set_metric: (P|Q) not positive definite at pivot " + std::to_string(info));
-    return upload_linv(h, L.data());
+    return upload_linv_from_device(h, w);
+}
+
+int32_t jcdf_device_potrf_trtri(int32_t device_id, double *A, int64_t n)
+{
+    if (!A || n <= 0) return JCDF_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return JCDF_ERR_NO_DEVICE;
+    CholBuffers w;
+    int info = 0;
+    hipError_t e = chol_inverse_device(nullptr, A, n, w, &info);
+    if (e == hipErrorOutOfMemory) return JCDF_ERR_ALLOC;
+    if (e != hipSuccess) return JCDF_ERR_HIP;
+    if (info != 0) return JCDF_ERR_NOT_SPD;
+    // column-major lower L^-1[q + n s] = V[s][q]; the strict upper triangle of V's rows is what is
+    // non-zero, so the returned matrix has an exactly-zero upper triangle (like the reference's trtri + zeroing)
+    if (hipMemcpy2D(A, (size_t)n * 8, w.V, (size_t)w.ld * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        return JCDF_ERR_HIP;
+    return JCDF_OK;
 }
 
 int32_t jcdf_push_three_center(jcdf_handle *h, int64_t s0, int64_t s1, const double *T)

@@ -464,8 +464,20 @@ def lapack_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
     return np.asfortranarray(np.tril(inv))
 
 
+def device_potrf_trtri(J2c: np.ndarray, device_id: int = 0) -> np.ndarray:
+    """L^-1 via the library's blocked fp64-MFMA device factorisation (what jcdf_set_metric runs;
+    CUSOLVER.potrf!/trtri! at DenseGPUDF.jl:185-193)."""
+    a = np.array(J2c, dtype=np.float64, order="F", copy=True)
+    if a.ndim != 2 or a.shape[0] != a.shape[1] or a.shape[0] == 0:
+        raise JCDFError(1, "device_potrf_trtri: square non-empty matrix expected")
+    rc = _lib.load().jcdf_device_potrf_trtri(_physical_device(device_id), a.ctypes.data, a.shape[0])
+    if rc != 0:
+        raise JCDFError(rc, "device potrf/trtri failed (status %d%s)" % (rc, ": not positive definite" if rc == 5 else ""))
+    return a
+
+
 def host_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
-    """L^-1 via the library's dependency-free host Cholesky/inverse (what jcdf_set_metric runs)."""
+    """L^-1 via the library's dependency-free host Cholesky/inverse (JCDF_HOST_CHOLESKY=1 path of jcdf_set_metric)."""
     a = np.array(J2c, dtype=np.float64, order="F", copy=True)
     rc = _lib.load().jcdf_host_potrf_trtri(a.ctypes.data, a.shape[0])
     if rc != 0:
@@ -537,7 +549,7 @@ def _comm() -> Tuple[int, int, Any]:
 def calculate_B_GPU(scf_data: SCFData, engine: DFIntegralEngine, two_center_integrals: np.ndarray,
                     num_devices: int, basis_sets: CalculationBasisSets, jc_timing: JCTiming) -> None:
     """B = L^-1 (Q|pq) on the devices (GPUDF.jl:828-1008).  potrf/trtri on the
-    host (:890-891); every T row block s is produced by its owner and pushed to
+    device (reference: host LAPACK at :890-891, cuSOLVER at DenseGPUDF.jl:185-193); every T row block s is produced by its owner and pushed to
     every handle r with rows_r >= rows_s (L^-1 lower triangular, SURVEY 3.4);
     across processes the block travels by broadcast (reference: host-staged
     MPI.Send/Recv!, :918-997)."""
@@ -547,10 +559,9 @@ def calculate_B_GPU(scf_data: SCFData, engine: DFIntegralEngine, two_center_inte
     gd.device_Q_indices = ranges
     gd.device_Q_range_lengths = [len(r) for r in ranges]
     t0 = time.perf_counter()
-    Linv = lapack_potrf_trtri(two_center_integrals)
+    for h in gd.handles:                 # potrf + trtri on each device (DenseGPUDF.jl:185-193 placement)
+        h.set_metric(two_center_integrals)
     jc_timing.timings[JCTC.form_J_AB_inv_time] = time.perf_counter() - t0
-    for h in gd.handles:
-        h.set_metric_inverse(Linv)
     t_eri = 0.0
     t0 = time.perf_counter()
     for g, rows in enumerate(ranges):

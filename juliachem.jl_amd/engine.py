@@ -118,7 +118,7 @@ class DeviceFockBuilder:
 
     # ---- setup -----------------------------------------------------------------
     def set_metric(self, J2c: np.ndarray) -> None:
-        self.h.set_metric_inverse(lapack_potrf_trtri(J2c))   # LAPACK potrf/trtri on the host, GPUDF.jl:890-891
+        self.h.set_metric(J2c)   # device potrf/trtri (DenseGPUDF.jl:185-193; host LAPACK at GPUDF.jl:890-891)
 
     def set_core_hamiltonian(self, H: np.ndarray) -> None:
         self.h.set_core_hamiltonian(H if self.rank == 0 else None)     # GPUDF.jl:158-161

@@ -378,3 +378,60 @@ def test_degenerate_sizes(N, Q, o):
     ref = s.H + orc.df_rhf_fock_build_BLAS(B, Co)
     assert _rel(F, ref) < RTOL
     h.close()
+
+
+# ---- device potrf + trtri of the metric (csrc/jcdf_chol.hpp; DenseGPUDF.jl:185-193) ---------------
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 128, 129, 200, 333, 1000])
+def test_device_potrf_trtri_matches_lapack(n):
+    import scipy.linalg as sla
+    rng = np.random.default_rng(5 + n)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    upper_garbage = np.tril(A) + np.triu(np.full((n, n), np.nan), 1)      # only the lower triangle may be read
+    X = jc.device_potrf_trtri(upper_garbage)
+    Li = sla.solve_triangular(sla.cholesky(A, lower=True), np.eye(n), lower=True)
+    assert np.allclose(X, Li, rtol=0, atol=1e-12 * np.abs(Li).max())
+    assert np.all(np.triu(X, 1) == 0.0)
+    # L^-T L^-1 == A^-1 to the conditioning of A
+    assert np.allclose(X.T @ X @ A, np.eye(n), atol=1e-10)
+
+
+def test_device_potrf_trtri_ill_conditioned_metric():
+    """A Coulomb-metric-like matrix (smooth kernel, condition ~1e8): compare through the fitted
+    quantity L^-1 (P|Q) L^-T == 1 instead of element-wise."""
+    n = 300
+    x = np.linspace(0.0, 1.0, n)
+    A = np.exp(-40.0 * (x[:, None] - x[None, :]) ** 2) + 1e-8 * np.eye(n)
+    X = jc.device_potrf_trtri(np.tril(A))
+    Xl = jc.lapack_potrf_trtri(np.tril(A))
+    assert np.abs(X @ A @ X.T - np.eye(n)).max() <= 10 * max(np.abs(Xl @ A @ Xl.T - np.eye(n)).max(), 1e-12)
+
+
+def test_device_potrf_rejects_non_spd():
+    with pytest.raises(jc.JCDFError) as e:
+        jc.device_potrf_trtri(-np.eye(4))
+    assert e.value.code == 5
+    A = np.eye(200)
+    A[150, 150] = -1.0                                                    # fails in the third 64-block
+    with pytest.raises(jc.JCDFError) as e:
+        jc.device_potrf_trtri(A)
+    assert e.value.code == 5
+
+
+def test_set_metric_device_vs_host_cholesky(monkeypatch):
+    """jcdf_set_metric: device factorisation (default) and the host one (JCDF_HOST_CHOLESKY=1) give the same B."""
+    N, Q, o = 40, 333, 4
+    s = synthetic.make(N, Q, o, seed=9)
+    T = np.asfortranarray(s.T.reshape(Q, N * N, order="F"))
+    out = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("JCDF_HOST_CHOLESKY", "1")
+        h = _handle(N, Q, 100, 280, o)                                    # a middle shard
+        h.set_metric(np.tril(s.J2c))
+        h.push_three_center(0, Q, T)
+        out.append(h.get_B())
+        h.close()
+    assert _rel(out[0], out[1]) < 1e-11
+    Bref = orc.calculate_B(s.J2c, s.T).reshape(Q, N * N, order="F")[100:280]
+    assert _rel(out[0], Bref) < 1e-10
