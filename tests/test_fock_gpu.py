@@ -435,3 +435,44 @@ def test_set_metric_device_vs_host_cholesky(monkeypatch):
     assert _rel(out[0], out[1]) < 1e-11
     Bref = orc.calculate_B(s.J2c, s.T).reshape(Q, N * N, order="F")[100:280]
     assert _rel(out[0], Bref) < 1e-10
+
+
+def test_rccl_backend_single_rank_collectives(tmp_path):
+    """The production backend ("nccl" == RCCL) on the one GPU of the test box: a 1-rank group runs the
+    same broadcast / all-reduce calls the engine issues on fp64 DEVICE tensors (no host staging), ordered
+    against the library's kernels on torch's current stream.  Multi-rank arithmetic is covered by the gloo tests."""
+    import subprocess, sys, os, textwrap
+    script = tmp_path / "rccl1.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import juliachem_jl_amd as jc
+        from juliachem_jl_amd import synthetic
+        from juliachem_jl_amd.engine import DeviceFockBuilder, _all_reduce, _broadcast, _staged
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        N, Q, o = 40, 96, 5
+        s = synthetic.make(N, Q, o, seed=3)
+        fb = DeviceFockBuilder(N, Q, o, [4] * (Q // 4), device=0)
+        assert fb.world == 1 and fb.dist is not None
+        fb.set_metric(s.J2c); fb.set_core_hamiltonian(s.H)
+        T = torch.as_tensor(np.ascontiguousarray(s.T.transpose(2, 1, 0)), device="cuda").reshape(-1)
+        blk = T.clone()
+        assert not _staged(dist, blk)
+        _broadcast(dist, blk, 0)                       # ncclBroadcast on the device buffer
+        fb.push_three_center_device(0, Q, blk)
+        C = torch.as_tensor(np.ascontiguousarray(s.C[:, :o].T), device="cuda")
+        fb.h.fock_build_device(C.data_ptr(), fb.F.data_ptr())
+        _all_reduce(dist, fb.F)                        # ncclAllReduce(N^2 fp64) right behind the kernels
+        F = fb.F.cpu().numpy()
+        np.save(%r, F)
+        dist.destroy_process_group()
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "F.npy"))))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    s = synthetic.make(40, 96, 5, seed=3)
+    B = orc.calculate_B(s.J2c, s.T)
+    ref = s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :5])
+    assert _rel(np.load(tmp_path / "F.npy"), ref) < 1e-10
