@@ -186,6 +186,15 @@ int32_t jcdf_device_potrf_trtri(int32_t device_id, double *A, int64_t n);
 int64_t jcdf_sytrd_workspace_bytes(int64_t n);
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                           double *d_TAU, void *d_work, int64_t work_bytes);
+/* Same, and additionally d_Q (n x n, row-major == the transpose in column-major) receives the
+ * orthogonal matrix Q = H_0 H_1 ... of A = Q T Q^T, accumulated inside the same kernel while the
+ * reflectors travel between workgroups, so the eigenvectors of A are ONE GEMM Q*Z away (instead of
+ * LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
+ * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above). */
+int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
+                            double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
+int64_t jcdf_sytrd_max_n(int32_t with_q);
+
 
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */

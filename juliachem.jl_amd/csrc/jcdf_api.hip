@@ -889,52 +889,64 @@ int32_t jcdf_host_potrf_trtri(double *A, int64_t n)
 }
 
 // ---- replicated eigensolve helper (caller side) ----------------------------
-static int sytrd_groups(int64_t n, size_t *lds_bytes)
+static size_t sytrd_lds(int64_t n, int G, bool with_q)
 {
-    // fewest workgroups that hold the matrix in LDS, but at least the measured sweet spot
-    // (tools/eigbench3.py: n = 240 -> 32, n = 510 -> 64 workgroups; flat between 32 and 128)
+    return (size_t)((with_q ? 2 : 1) * ((n + G - 1) / G) * n + 2 * n + 32) * 8;
+}
+
+static int sytrd_groups(int64_t n, bool with_q, size_t *lds_bytes)
+{
+    // fewest workgroups that hold the matrix (and, with_q, the rows of Q) in LDS, but at least the
+    // measured sweet spot (tools/eigbench3.py: n = 240 -> 32, n = 510 -> 64 workgroups; flat between 32 and 128)
     int G = n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1));
+    while (sytrd_lds(n, G, with_q) > 150 * 1024 && G < 256) G *= 2;
     const char *env = getenv("JCDF_SYTRD_G");
-    for (;;) {
-        const size_t lds = (size_t)(((n + G - 1) / G) * n + 2 * n + 16) * 8;
-        if (lds <= 150 * 1024 || G >= 256) { *lds_bytes = lds; break; }
-        G *= 2;
-    }
     if (env) {
         const int want = atoi(env);
-        if (want >= 1 && want <= 256 && (size_t)(((n + want - 1) / want) * n + 2 * n + 16) * 8 <= 160 * 1024) {
-            G = want;
-            *lds_bytes = (size_t)(((n + G - 1) / G) * n + 2 * n + 16) * 8;
-        }
+        if (want >= 1 && want <= 256 && sytrd_lds(n, want, with_q) <= 160 * 1024) G = want;
     }
+    *lds_bytes = sytrd_lds(n, G, with_q);
     return G;
 }
 
 int64_t jcdf_sytrd_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    // err word (64 B header) + granule pairs: v 2(n+1), y 2n, dots 2*256; 16 B per pair
+    // err word (64 B header) + granule pairs: v 2(n+1), y 2n (+ 512 spare); 16 B per pair
     return 64 + (int64_t)(2 * (n + 1) + 2 * n + 2 * 256) * 16;
+}
+
+int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
+                            double *d_Q, void *d_work, int64_t work_bytes)
+{
+    if (n <= 0 || !d_A || lda < n || !d_D || !d_E || !d_TAU || !d_work || work_bytes < jcdf_sytrd_workspace_bytes(n))
+        return JCDF_ERR_INVALID;
+    size_t lds = 0;
+    const int G = sytrd_groups(n, d_Q != nullptr, &lds);
+    if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // n too large for LDS residency
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)d_work;
+    int *err = (int *)(w + 8);
+    jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 4 * (n + 1);
+    // tags restart at 1 every call: all granules (and the error word) are zeroed first
+    if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
+    (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
+                       err, d_Q);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
                           void *d_work, int64_t work_bytes)
 {
-    if (n <= 0 || !d_A || lda < n || !d_D || !d_E || !d_TAU || !d_work || work_bytes < jcdf_sytrd_workspace_bytes(n))
-        return JCDF_ERR_INVALID;
-    size_t lds = 0;
-    const int G = sytrd_groups(n, &lds);
-    if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // n too large for LDS residency (n <~ 2200)
-    hipStream_t st = (hipStream_t)stream;
-    char *w = (char *)d_work;
-    int *err = (int *)(w + 8);
-    jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 4 * (n + 1), *dg = yg + 4 * n;
-    // tags restart at 1 every call: all granules (and the error word) are zeroed first
-    if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
-    (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
-                       dg, err);
-    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+    return jcdf_sytrd_q_device(stream, n, d_A, lda, d_D, d_E, d_TAU, nullptr, d_work, work_bytes);
+}
+
+int64_t jcdf_sytrd_max_n(int32_t with_q)
+{
+    int64_t n = 64;
+    while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;
+    return n;
 }
 
 int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }

@@ -33,6 +33,13 @@ namespace jcdf {
 // tridiagonalisation: per column there are two store->load hops (v, then y) instead of six.
 typedef unsigned long long u64;
 
+#ifdef JCDF_SYTRD_PROFILE   // tools/sytrd_prof.hip: per-phase wall-clock ticks (100 MHz) of workgroup 1, summed over columns
+__device__ u64 g_sytrd_prof[8];
+#define SYTRD_TICK(slot) do { if (g == 1 && tid == 0) { const u64 t_ = wall_clock64(); g_sytrd_prof[slot] += t_ - tprof; tprof = t_; } } while (0)
+#else
+#define SYTRD_TICK(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ void pub(u64 *g, int idx, double v, unsigned tag)
 {
     const u64 bits = (u64)__double_as_longlong(v);
@@ -103,37 +110,105 @@ __device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int co
     return true;
 }
 
-__device__ __forceinline__ double block_sum(double x, double *red)
+// ---- reductions on the VALU (DPP), not through the LDS crossbar ------------------------------
+// (a double __shfl_xor is two ds_bpermute_b32; with four waves reducing eight values each the LDS
+// pipe, not arithmetic, set the time of a step: tools/sytrd_prof.hip)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);       // +0.0 in rows outside ROW_MASK
+}
+
+// after this every lane holds the sum over its row of 16 lanes
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += dpp_f64<0xB1, 0xf>(x);      // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E, 0xf>(x);      // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141, 0xf>(x);     // row_half_mirror
+    x += dpp_f64<0x140, 0xf>(x);     // row_mirror
+    return x;
+}
+
+// lane 31 <- sum over lanes 0..31, lane 63 <- sum over lanes 32..63 (other lanes: partial values)
+__device__ __forceinline__ double half_sums(double x)
+{
+    x = row16_sum(x);
+    x += dpp_f64<0x142, 0xa>(x);     // row_bcast:15 into rows 1 and 3
+    return x;
+}
+
+// sum over the 64 lanes, returned in every lane
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x = half_sums(x);
+    x += dpp_f64<0x143, 0xc>(x);     // row_bcast:31 into rows 2 and 3
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// Block-wide sums with ONE barrier: `red` holds two alternating banks of 16 doubles, `rs` is a
+// per-thread call counter (call N+2 may overwrite bank N&1 because every thread passed the barrier
+// of call N+1 after it read bank N&1).
+__device__ __forceinline__ double block_sum(double x, double *red, unsigned &rs)
+{
+    double *bank = red + 16 * (rs++ & 1);
+    x = wave_sum(x);
+    if ((threadIdx.x & 63) == 0) bank[threadIdx.x >> 6] = x;
     __syncthreads();
     double s = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += bank[w];
     return s;
 }
 
-// true iff every thread of the workgroup passes `ok`
-__device__ __forceinline__ bool block_all(bool ok, double *red)
+__device__ __forceinline__ void block_sum2(double &x, double &y, double *red, unsigned &rs)
 {
-    return block_sum(ok ? 0.0 : 1.0, red) == 0.0;
+    double *bank = red + 16 * (rs++ & 1);
+    x = wave_sum(x);
+    y = wave_sum(y);
+    if ((threadIdx.x & 63) == 0) {
+        bank[threadIdx.x >> 6] = x;
+        bank[8 + (threadIdx.x >> 6)] = y;
+    }
+    __syncthreads();
+    double sx = 0.0, sy = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        sx += bank[w];
+        sy += bank[8 + w];
+    }
+    x = sx;
+    y = sy;
 }
 
+// true iff every thread of the workgroup passes `ok`
+__device__ __forceinline__ bool block_all(bool ok, double *red, unsigned &rs)
+{
+    return block_sum(ok ? 0.0 : 1.0, red, rs) == 0.0;
+}
+
+constexpr int SYTRD_CB = 8;      // local columns processed together (independent accumulators)
+
 // A: n x n symmetric (full storage, lda >= n).  Workspace: `err` word + granule buffers
-//   vg: 2 x (n+1) granule pairs (slot n of a half carries tau), yg: 2 x n, dg: 2 x gridDim.x,
+//   vg: 2 x (n+1) granule pairs (slot n of a half carries tau), yg: 2 x n,
 // all zeroed before launch (tags start at 1).
-// LDS: (ncol_max * n + 2 n + 16) doubles, ncol_max = ceil(n / gridDim.x).
+// LDS: ((Qout ? 2 : 1) * ncol_max * n + 2 n + 32) doubles, ncol_max = ceil(n / gridDim.x).
+// Qout (optional, n x n row-major): the orthogonal matrix Q = H_0 H_1 ... H_{n-3} of A = Q T Q^T,
+// accumulated on the fly (rows distributed like the columns of A), so eigenvectors of A are Q Z.
 //
-// Per column k:  owner publishes v_k, tau_k  ->  everyone: y = tau A22 v for its own columns,
-// publishes y and its partial v.y  ->  everyone: w, rank-2 update of its own columns; the owner of
-// column k+1 updates that column FIRST and publishes v_{k+1} before it updates the rest.
+// Per column k:  owner publishes v_k, tau_k  ->  everyone: y = tau A22 v for its own columns (32 lanes
+// per column, SYTRD_CB columns at a time, DPP reduction, no barrier), publishes y  ->  everyone: y.v
+// (redundantly, no exchange), w, rank-2 update of its own columns; the owner of column k+1 updates that column FIRST
+// (the norm of the new reflector is accumulated in the same pass) and publishes v_{k+1} before it
+// updates the rest.
 // Buffer reuse (parity of k) is safe without barriers: v_{k+2} can only be formed after every
 // workgroup has published y_{k+1}, i.e. after it has consumed v_{k+1}, v_k and y_k.
 __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     u64 *vg, u64 *yg, u64 *dg, int *err)
+                                                     u64 *vg, u64 *yg, int *err, double *__restrict__ Qout)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -142,21 +217,24 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     double *slab = lds;                                   // column c (global j = g + c G) at slab + c*n
     double *vs = lds + (size_t)ncol_max * n;
     double *ws = vs + n;
-    double *red = ws + n;                                 // 8 doubles for reductions
+    double *red = ws + n;                                 // 2 x 16 doubles for reductions
+    double *qrow = red + 32;                              // Qout != nullptr: my rows g, g+G, ... of Q, row r at qrow + r*n
+    unsigned rs = 0;
+    if (Qout)
+        for (int r = 0; r < nc; ++r)
+            for (int i = tid; i < n; i += nthr) qrow[(size_t)r * n + i] = (i == g + r * G) ? 1.0 : 0.0;
 
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) slab[(size_t)c * n + i] = A[(size_t)(g + c * G) * lda + i];
     __syncthreads();
 
-    // dlarfg on x = A[k+1:n, k] (column k is local column k / G of its owner); publishes v_k, tau_k
-    auto reflector = [&](int k) {
+    // dlarfg on x = A[k+1:n, k] (column k is local column k / G of its owner) given xnorm2 = |x[1:]|^2;
+    // publishes v_k, tau_k.  Called by every thread of the owner.
+    auto reflector = [&](int k, double xnorm2) {
         const int m = n - k - 1, buf = k & 1;
         const unsigned tag = (unsigned)(k + 1);
         u64 *vb = vg + (size_t)buf * 2 * (n + 1);
         double *x = slab + (size_t)(k / G) * n + (k + 1);
-        double part = 0.0;
-        for (int i = 1 + tid; i < m; i += nthr) part += x[i] * x[i];
-        const double xnorm2 = block_sum(part, red);
         const double alpha = x[0];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (xnorm2 != 0.0) {
@@ -164,7 +242,7 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             tau = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        __syncthreads();
+        __syncthreads();                                  // everyone has read x[0]
         if (tid == 0) pub(vb, n, tau, tag);
         for (int i = tid; i < m; i += nthr) {
             const double v = (i == 0) ? 1.0 : x[i] * scale;
@@ -179,81 +257,140 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
         }
     };
 
-    if (n > 1 && g == 0) reflector(0);
+#ifdef JCDF_SYTRD_PROFILE
+    u64 tprof = wall_clock64();
+#endif
+    if (n > 1 && g == 0) {
+        double part = 0.0;
+        for (int i = 2 + tid; i < n; i += nthr) part += slab[i] * slab[i];
+        reflector(0, block_sum(part, red, rs));
+    }
     for (int k = 0; k < n - 1; ++k) {
         const int m = n - k - 1;                          // rows k+1 .. n-1
         const int buf = k & 1;
         const unsigned tag = (unsigned)(k + 1);
         const u64 *vb = vg + (size_t)buf * 2 * (n + 1);
         u64 *yb = yg + (size_t)buf * 2 * n;
-        u64 *db = dg + (size_t)buf * 2 * G;
 
         // ---- everyone: v, tau -> LDS (each thread waits for its own elements)
         bool ok = true;
         for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(vb, i0, nthr, m, tag, vs, err);
         if (tid == 0 && ok) ok = sub(vb, n, tag, vs + (n - 1), err);
-        if (!block_all(ok, red)) return;
+        if (!block_all(ok, red, rs)) return;
+        SYTRD_TICK(0);                                    // waited for v
         const double tau = vs[n - 1];
         const int c0 = (k + 1 - g + G - 1) / G;           // first local column with j > k
-        const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+        const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
 
-        // ---- y_j = tau * A22[:, j] . v for my columns j > k ; partial v.y
-        double dpart = 0.0;
         if (tau != 0.0) {
-            for (int c = c0 + wave; c < nc; c += nw) {
-                const double *col = slab + (size_t)c * n + (k + 1);
-                double s = 0.0;
-                for (int i = lane; i < m; i += 64) s += col[i] * vs[i];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                if (lane == 0) {
-                    const int j = g + c * G;
-                    const double y = tau * s;
-                    pub(yb, j - (k + 1), y, tag);
-                    dpart += vs[j - (k + 1)] * y;
+            // ---- y_j = tau * A22[:, j] . v for my columns j > k: 32 lanes per column, SYTRD_CB columns per pass
+            {
+                const int seg = tid & 31, ce = tid >> 5;
+                for (int cb = c0; cb < nc; cb += SYTRD_CB) {
+                    const bool have = cb + ce < nc;
+                    const double *col = slab + (size_t)(have ? cb + ce : c0) * n + (k + 1);
+                    double s0 = 0.0, s1 = 0.0;
+                    int i = seg;
+                    for (; i + 32 < m; i += 64) {
+                        s0 += col[i] * vs[i];
+                        s1 += col[i + 32] * vs[i + 32];
+                    }
+                    if (i < m) s0 += col[i] * vs[i];
+                    const double s = half_sums(s0 + s1);
+                    if (seg == 31 && have) {
+                        const int j = g + (cb + ce) * G;
+                        pub(yb, j - (k + 1), tau * s, tag);
+                    }
                 }
             }
-            dpart = block_sum(dpart, red);                // lane 0 of each wave carried its partial
-            if (tid == 0) pub(db, g, dpart, tag);
-        }
+            SYTRD_TICK(1);                                // y for my columns
 
-        // ---- everyone: w = y - (tau/2)(y.v) v ; A22[:, j] -= v w_j + w v_j for my columns j > k
-        const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
-        if (tau != 0.0) {
-            double dl = 0.0;
-            for (int q = tid; q < G && ok; q += nthr) {
-                double dq;
-                ok = sub(db, q, tag, &dq, err);
-                dl += dq;
+            // ---- while y travels: Q <- Q H_k on my rows of Q (needs only v_k; same lanes own the same
+            //      elements in every step, so no barrier).  Replaces the ormtr back-transformation by one GEMM.
+            if (Qout) {
+                const int seg = tid & 31, ce = tid >> 5;
+                for (int rb = 0; rb < nc; rb += SYTRD_CB) {
+                    const bool have = rb + ce < nc;
+                    double *q = qrow + (size_t)(have ? rb + ce : 0) * n + (k + 1);
+                    double s0 = 0.0, s1 = 0.0;
+                    int i = seg;
+                    for (; i + 32 < m; i += 64) {
+                        s0 += q[i] * vs[i];
+                        s1 += q[i + 32] * vs[i + 32];
+                    }
+                    if (i < m) s0 += q[i] * vs[i];
+                    const double h = half_sums(s0 + s1);
+                    const long long hb = __double_as_longlong(h);
+                    const int lo31 = __builtin_amdgcn_readlane((int)(hb & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb >> 32), 31);
+                    const int lo63 = __builtin_amdgcn_readlane((int)(hb & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb >> 32), 63);
+                    const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
+                                                  : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
+                    const double sc = tau * tot;
+                    if (have)
+                        for (int i2 = seg; i2 < m; i2 += 32) q[i2] -= sc * vs[i2];
+                }
             }
+            SYTRD_TICK(4);                                // Q accumulation
+
+            // ---- everyone: full y -> LDS, y.v, w = y - (tau/2)(y.v) v
             for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(yb, i0, nthr, m, tag, ws, err);   // ws = y for now
-            if (!block_all(ok, red)) return;
-            const double al = -0.5 * tau * block_sum(dl, red);
+            double bad = ok ? 0.0 : 1.0, dot = 0.0;
+            if (ok)
+                for (int i = tid; i < m; i += nthr) dot += ws[i] * vs[i];   // each thread re-reads only what it wrote
+            block_sum2(bad, dot, red, rs);
+            if (bad != 0.0) return;
+            SYTRD_TICK(2);                                // waited for y
+            const double al = -0.5 * tau * dot;
             for (int i = tid; i < m; i += nthr) ws[i] += al * vs[i];
             __syncthreads();
+
+            // ---- A22[:, j] -= v w_j + w v_j for my columns j > k
             int cfirst = c0;
             if (next_owner) {                             // column k+1 first, then its reflector goes out
                 double *col = slab + (size_t)c0 * n + (k + 1);           // local column c0 is j = k+1
-                for (int i = tid; i < m; i += nthr) col[i] -= vs[i] * ws[0] + ws[i] * vs[0];
-                __syncthreads();
-                reflector(k + 1);
+                const double w0 = ws[0], v0 = vs[0];
+                double part = 0.0;
+                for (int i = tid; i < m; i += nthr) {
+                    const double x = col[i] - (vs[i] * w0 + ws[i] * v0);
+                    col[i] = x;
+                    if (i >= 2) part += x * x;
+                }
+                reflector(k + 1, block_sum(part, red, rs));
                 cfirst = c0 + 1;
             }
-            for (int c = cfirst + wave; c < nc; c += nw) {              // one wave per column, lanes along the rows
-                const int jj = g + c * G - (k + 1);
-                const double wj = ws[jj], vj = vs[jj];
-                double *col = slab + (size_t)c * n + (k + 1);
-                for (int i = lane; i < m; i += 64) col[i] -= vs[i] * wj + ws[i] * vj;
+            for (int cb = cfirst; cb < nc; cb += SYTRD_CB) {
+                const int ne = nc - cb;
+                double wj[SYTRD_CB], vj[SYTRD_CB];
+#pragma unroll
+                for (int e = 0; e < SYTRD_CB; ++e) {
+                    const int jj = g + (cb + (e < ne ? e : 0)) * G - (k + 1);
+                    wj[e] = ws[jj];
+                    vj[e] = vs[jj];
+                }
+                double *base = slab + (size_t)cb * n + (k + 1);
+                for (int i = tid; i < m; i += nthr) {
+                    const double vi = vs[i], wi = ws[i];
+#pragma unroll
+                    for (int e = 0; e < SYTRD_CB; ++e)
+                        if (e < ne) base[(size_t)e * n + i] -= vi * wj[e] + wi * vj[e];
+                }
             }
         } else if (next_owner) {
-            reflector(k + 1);
+            double *col = slab + (size_t)c0 * n + (k + 1);
+            double part = 0.0;
+            for (int i = 2 + tid; i < m; i += nthr) part += col[i] * col[i];
+            reflector(k + 1, block_sum(part, red, rs));
         }
         __syncthreads();
+        SYTRD_TICK(3);                                    // rank-2 update (+ reflector when next owner)
     }
     if (g == (n - 1) % G && tid == 0) D[n - 1] = slab[(size_t)((n - 1) / G) * n + (n - 1)];
     __syncthreads();
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
+    if (Qout)
+        for (int r = 0; r < nc; ++r)
+            for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * n + i] = qrow[(size_t)r * n + i];
 }
 
 }  // namespace jcdf

@@ -3,11 +3,12 @@ SURVEY 8 row f1; reference: `eigen!(Hermitian(F'))`, SCF.jl:1083).
 
 rocSOLVER's syevd needs ~4000 tiny launches for the tridiagonalisation (9 of its 12 ms at
 N = 510).  Here the tridiagonalisation is ONE persistent kernel of libjcdf_hip.so
-(`jcdf_sytrd_device`, csrc/jcdf_eig.hpp) and only the remaining two LAPACK steps use the
-vendor library already in the process (PyTorch's librocsolver): stedc (divide & conquer on
-the tridiagonal matrix) and ormtr (back-transformation by the Householder reflectors).
-Falls back to torch.linalg.eigh when the vendor entry points are unavailable or the
-in-kernel grid barrier reports a timeout.
+(`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp) which also accumulates the orthogonal factor Q while
+its reflectors travel between workgroups (A = Q T Q^T), so the back-transformation is one GEMM
+Q Z instead of LAPACK's ormtr (~30 launches, 1.1 ms).  Only stedc (divide & conquer on the
+tridiagonal matrix) still uses the vendor library already in the process (PyTorch's librocsolver).
+Matrices too large for Q to stay in LDS use ormtr.  Falls back to torch.linalg.eigh when the vendor
+entry points are unavailable or an in-kernel hand-off reports a timeout.
 """
 from __future__ import annotations
 
@@ -48,6 +49,8 @@ class DeviceEigh:
             wb = int(self.lib.jcdf_sytrd_workspace_bytes(n))
             self.work = torch.zeros(wb // 8 + 1, **f64)
             self.wb = wb
+            self.with_q = n <= int(self.lib.jcdf_sytrd_max_n(1)) and not os.environ.get("JCDF_EIGH_ORMTR")
+            self.Q = torch.empty((n, n), **f64) if self.with_q else None
             self.ok = True
         except Exception as e:                                    # vendor library not loadable: plain torch path
             self.reason = repr(e)
@@ -63,11 +66,14 @@ class DeviceEigh:
         self.rb.rocblas_set_stream(self.handle, C.c_void_p(st))
         self.A.copy_(Fp)
         p = lambda t: C.c_void_p(t.data_ptr())
-        rc = self.lib.jcdf_sytrd_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
-                                        p(self.work), self.wb)
+        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
+                                          p(self.Q) if self.with_q else None, p(self.work), self.wb)
         if rc == 0:
             rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
                                           p(self.info))
+        if rc == 0 and self.with_q:
+            # Cm holds Z column-major == Z^T as a row-major tensor; Q is row-major: U = Q Z
+            return self.D, self.Q @ self.Cm.T
         if rc == 0:
             rc = self.rs.rocsolver_dormtr(self.handle, _SIDE_LEFT, _FILL_LOWER, _OP_NONE, n, n, p(self.A), n,
                                           p(self.TAU), p(self.Cm), n)

@@ -298,11 +298,15 @@ def test_water_golden_energy_trail_on_gpu():
     fb.close()
 
 
-@pytest.mark.parametrize("n", [3, 25, 64, 130, 257, 510, 700])
-def test_device_eigh_matches_lapack(n):
-    """Persistent-kernel tridiagonalisation + stedc + ormtr vs numpy (LAPACK) eigh."""
+@pytest.mark.parametrize("n,ormtr", [(3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0), (1250, 0),
+                                     (64, 1), (130, 1), (510, 1)])
+def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
+    """Persistent-kernel tridiagonalisation (+ in-kernel Q accumulation and one GEMM, or ormtr) + stedc
+    vs numpy (LAPACK) eigh."""
     import torch
     from juliachem_jl_amd.eigh import DeviceEigh
+    if ormtr:
+        monkeypatch.setenv("JCDF_EIGH_ORMTR", "1")
     rng = np.random.default_rng(n)
     A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
     if n == 64:                                   # degenerate spectrum + zero sub-columns (tau == 0 branches)
@@ -310,6 +314,7 @@ def test_device_eigh_matches_lapack(n):
     dev = torch.device("cuda", 0)
     eg = DeviceEigh(n, dev)
     assert eg.ok, getattr(eg, "reason", "")
+    assert eg.with_q == (not ormtr)
     w, U = eg(torch.as_tensor(A, device=dev))
     torch.cuda.synchronize()
     assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")

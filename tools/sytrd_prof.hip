@@ -1,0 +1,64 @@
+// Phase timeline of k_sytrd_lower (workgroup 1): hipcc --offload-arch=gfx950 -O3 -DJCDF_SYTRD_PROFILE -o sytrd_prof sytrd_prof.hip
+#include "../juliachem.jl_amd/csrc/jcdf_eig.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+using namespace jcdf;
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 510;
+    const int G = argc > 2 ? atoi(argv[2]) : 64;
+    std::vector<double> A((size_t)n * n);
+    srand(1);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) A[(size_t)i * n + j] = A[(size_t)j * n + i] = rand() / (double)RAND_MAX - 0.5;
+    double *dA, *dD, *dE, *dT;
+    char *w;
+    const size_t wb = 64 + (size_t)(2 * (n + 1) + 2 * n + 2 * 256) * 16;
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dD, n * 8); hipMalloc(&dE, n * 8); hipMalloc(&dT, n * 8); hipMalloc(&w, wb);
+    const int ncol = (n + G - 1) / G;
+    const bool withq = argc > 3 ? atoi(argv[3]) != 0 : true;
+    const size_t lds = ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
+    double *dQ; hipMalloc(&dQ, A.size() * 8);
+    hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+        hipMemset(w, 0, wb);
+        u64 zero[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_sytrd_prof), zero, sizeof(zero));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(256), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
+                           (u64 *)(w + 64) + 4 * (n + 1), (int *)(w + 8), withq ? dQ : nullptr);
+        hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        u64 p[8]; hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sytrd_prof), sizeof(p));
+        int err; hipMemcpy(&err, w + 8, 4, hipMemcpyDeviceToHost);
+        std::vector<double> d(n), e(n);
+        hipMemcpy(d.data(), dD, n * 8, hipMemcpyDeviceToHost); hipMemcpy(e.data(), dE, n * 8, hipMemcpyDeviceToHost);
+        double tr = 0, trT = 0, fr = 0, frT = 0;
+        for (int i = 0; i < n; ++i) { tr += A[(size_t)i * n + i]; trT += d[i]; frT += d[i] * d[i] + (i < n - 1 ? 2 * e[i] * e[i] : 0); }
+        for (size_t i = 0; i < A.size(); ++i) fr += A[i] * A[i];
+        printf("   invariants: trace %.3e  frob^2 rel %.3e\n", tr - trT, (fr - frT) / fr);
+        printf("n=%d G=%d lds=%zu: %.3f ms (%.2f us/col) err=%d | per column us: wait_v %.2f  y %.2f  Q %.2f  wait_y %.2f  update %.2f\n", n, G, lds, ms,
+               1e3 * ms / n, err, p[0] / 100.0 / n, p[1] / 100.0 / n, p[4] / 100.0 / n, p[2] / 100.0 / n, p[3] / 100.0 / n);
+    }
+    if (withq) {          // Q^T A Q == T and Q^T Q == I
+        std::vector<double> Q(A.size()), d(n), e(n), AQ(A.size());
+        hipMemcpy(Q.data(), dQ, A.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(d.data(), dD, n * 8, hipMemcpyDeviceToHost); hipMemcpy(e.data(), dE, n * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += A[(size_t)i * n + k] * Q[(size_t)k * n + j]; AQ[(size_t)i * n + j] = s; }
+        double emax = 0, omax = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double s = 0, o = 0;
+                for (int k = 0; k < n; ++k) { s += Q[(size_t)k * n + i] * AQ[(size_t)k * n + j]; o += Q[(size_t)k * n + i] * Q[(size_t)k * n + j]; }
+                const double t = i == j ? d[i] : (i == j + 1 ? e[j] : (j == i + 1 ? e[i] : 0.0));
+                emax = fmax(emax, fabs(s - t)); omax = fmax(omax, fabs(o - (i == j)));
+            }
+        printf("   Q check: |Q^T A Q - T|max %.3e   |Q^T Q - I|max %.3e\n", emax, omax);
+    }
+    return 0;
+}
