@@ -24,13 +24,17 @@
 namespace jcdf {
 
 // ---- tagged hand-off granules -----------------------------------------------------------
-// A handed-off double travels as two naturally aligned 8-byte words {tag32, half32}, each written
-// by ONE agent-scope relaxed atomic store (sc1, write-through) and read by agent-scope relaxed
-// atomic loads (sc1, bypass L1): "the data IS the flag" (cdna_hip_programming.md Guideline 16,
-// recipe R2: 8-byte {tag, value} granules need no flag, no fence and no ordering).  The tag is
-// the step number, so a consumer simply re-reads until both tags match; stale contents of the
-// reused buffers can never be mistaken for fresh data.  This removes every grid barrier from the
-// tridiagonalisation: per column there are two store->load hops (v, then y) instead of six.
+// A handed-off double travels as ONE naturally aligned 8-byte word written by ONE agent-scope relaxed
+// atomic store (sc1, write-through) and read by agent-scope relaxed atomic loads (sc1, bypass L1):
+// "the data IS the flag" (cdna_hip_programming.md Guideline 16, recipe R2: tagged 8-byte granules need
+// no flag, no fence and no ordering).  The tag is a 2-bit sequence number kept in the two lowest
+// mantissa bits: sender and receivers all compute with the value whose two low bits are zero (a
+// relative perturbation <= 3 * 2^-52, the size of one rounding error of the dot products that
+// produce these numbers), so every workgroup sees bit-identical data.  A slot of buffer (k & 1) is
+// rewritten at EVERY step k (also when tau == 0), so the word it held before carries the tag of step
+// k - 2, which differs: stale contents can never be mistaken for fresh data, and the zero-filled
+// initial state carries tag 0 while steps 0 and 1 use tag 1.  Half the words of a {tag32, half32}
+// encoding: the hand-offs are bound by the number of polled words (tools/xcd_pingpong.hip).
 typedef unsigned long long u64;
 
 #ifdef JCDF_SYTRD_PROFILE   // tools/sytrd_prof.hip: per-phase wall-clock ticks (100 MHz) of workgroup 1, summed over columns
@@ -40,34 +44,45 @@ __device__ u64 g_sytrd_prof[8];
 #define SYTRD_TICK(slot) do { } while (0)
 #endif
 
+__device__ __forceinline__ unsigned step_tag(int k) { return (unsigned)((k >> 1) + 1) & 3u; }
+
+__device__ __forceinline__ double tag_trunc(double v)
+{
+    return __longlong_as_double(__double_as_longlong(v) & ~3LL);
+}
+
 __device__ __forceinline__ void pub(u64 *g, int idx, double v, unsigned tag)
 {
-    const u64 bits = (u64)__double_as_longlong(v);
-    __hip_atomic_store(g + 2 * idx, ((u64)tag << 32) | (bits & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 2 * idx + 1, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + idx, ((u64)__double_as_longlong(v) & ~3ULL) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bounded spin bookkeeping shared by the subscribers: false = give up (timeout or a peer failed)
+__device__ __forceinline__ bool spin_ok(unsigned &spins, u64 &t0, int *err)
+{
+    if (++spins == 64) t0 = wall_clock64();
+    if (spins > 64 && (spins & 63) == 0) {
+        if (wall_clock64() - t0 > 5000000ULL) {                                  // 50 ms at 100 MHz
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return true;
 }
 
 // Returns false on timeout / peer failure (error word set).
 __device__ __forceinline__ bool sub(const u64 *g, int idx, unsigned tag, double *out, int *err)
 {
-    u64 a, b;
+    u64 a;
     unsigned spins = 0;
     u64 t0 = 0;
     for (;;) {
-        a = __hip_atomic_load(g + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b = __hip_atomic_load(g + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) break;
-        if (++spins == 64) t0 = wall_clock64();
-        if (spins > 64 && (spins & 63) == 0) {
-            if (wall_clock64() - t0 > 5000000ULL) {                              // 50 ms at 100 MHz
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
+        a = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a & 3ULL) == tag) break;
+        if (!spin_ok(spins, t0, err)) return false;
     }
-    *out = __longlong_as_double((long long)(((b & 0xffffffffULL) << 32) | (a & 0xffffffffULL)));
+    *out = __longlong_as_double((long long)(a & ~3ULL));
     return true;
 }
 
@@ -82,30 +97,18 @@ __device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int co
     unsigned spins = 0;
     u64 t0 = 0;
     while (pending) {
-        u64 a[8], b[8];
+        u64 a[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (pending & (1u << e)) {
-                const int idx = first + e * stride;
-                a[e] = __hip_atomic_load(g + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b[e] = __hip_atomic_load(g + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (pending & (1u << e)) a[e] = __hip_atomic_load(g + first + e * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if ((pending & (1u << e)) && (unsigned)(a[e] >> 32) == tag && (unsigned)(b[e] >> 32) == tag) {
-                dst[first + e * stride] = __longlong_as_double((long long)(((b[e] & 0xffffffffULL) << 32) | (a[e] & 0xffffffffULL)));
+            if ((pending & (1u << e)) && (unsigned)(a[e] & 3ULL) == tag) {
+                dst[first + e * stride] = __longlong_as_double((long long)(a[e] & ~3ULL));
                 pending &= ~(1u << e);
             }
         if (!pending) break;
-        if (++spins == 64) t0 = wall_clock64();
-        if (spins > 64 && (spins & 63) == 0) {
-            if (wall_clock64() - t0 > 5000000ULL) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
+        if (!spin_ok(spins, t0, err)) return false;
     }
     return true;
 }
@@ -193,8 +196,10 @@ __device__ __forceinline__ bool block_all(bool ok, double *red, unsigned &rs)
 constexpr int SYTRD_CB = 8;      // local columns processed together (independent accumulators)
 
 // A: n x n symmetric (full storage, lda >= n).  Workspace: `err` word + granule buffers
-//   vg: 2 x (n+1) granule pairs (slot n of a half carries tau), yg: 2 x n,
-// all zeroed before launch (tags start at 1).
+//   vg: 2 x (n+1) granules (slot n of a half carries tau), yg: 2 x n,
+// all zeroed before launch.  `lazy`: s_sleep units a workgroup that does NOT own the next column
+// waits before it starts polling y (only the next owner is on the critical path; fewer polls on the
+// fabric shorten its hop).
 // LDS: ((Qout ? 2 : 1) * ncol_max * n + 2 n + 32) doubles, ncol_max = ceil(n / gridDim.x).
 // Qout (optional, n x n row-major): the orthogonal matrix Q = H_0 H_1 ... H_{n-3} of A = Q T Q^T,
 // accumulated on the fly (rows distributed like the columns of A), so eigenvectors of A are Q Z.
@@ -208,7 +213,7 @@ constexpr int SYTRD_CB = 8;      // local columns processed together (independen
 // workgroup has published y_{k+1}, i.e. after it has consumed v_{k+1}, v_k and y_k.
 __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     u64 *vg, u64 *yg, int *err, double *__restrict__ Qout)
+                                                     u64 *vg, u64 *yg, int *err, double *__restrict__ Qout, int lazy)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -232,20 +237,20 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     // publishes v_k, tau_k.  Called by every thread of the owner.
     auto reflector = [&](int k, double xnorm2) {
         const int m = n - k - 1, buf = k & 1;
-        const unsigned tag = (unsigned)(k + 1);
-        u64 *vb = vg + (size_t)buf * 2 * (n + 1);
+        const unsigned tag = step_tag(k);
+        u64 *vb = vg + (size_t)buf * (n + 1);
         double *x = slab + (size_t)(k / G) * n + (k + 1);
         const double alpha = x[0];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (xnorm2 != 0.0) {
             beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-            tau = (beta - alpha) / beta;
+            tau = tag_trunc((beta - alpha) / beta);
             scale = 1.0 / (alpha - beta);
         }
         __syncthreads();                                  // everyone has read x[0]
         if (tid == 0) pub(vb, n, tau, tag);
         for (int i = tid; i < m; i += nthr) {
-            const double v = (i == 0) ? 1.0 : x[i] * scale;
+            const double v = (i == 0) ? 1.0 : tag_trunc(x[i] * scale);
             pub(vb, i, v, tag);
             if (i > 0) x[i] = v;                          // LAPACK storage of the reflector
         }
@@ -268,9 +273,9 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     for (int k = 0; k < n - 1; ++k) {
         const int m = n - k - 1;                          // rows k+1 .. n-1
         const int buf = k & 1;
-        const unsigned tag = (unsigned)(k + 1);
-        const u64 *vb = vg + (size_t)buf * 2 * (n + 1);
-        u64 *yb = yg + (size_t)buf * 2 * n;
+        const unsigned tag = step_tag(k);
+        const u64 *vb = vg + (size_t)buf * (n + 1);
+        u64 *yb = yg + (size_t)buf * n;
 
         // ---- everyone: v, tau -> LDS (each thread waits for its own elements)
         bool ok = true;
@@ -282,11 +287,11 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
         const int c0 = (k + 1 - g + G - 1) / G;           // first local column with j > k
         const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
 
-        if (tau != 0.0) {
+        {   // tau == 0 (nothing to annihilate) runs the same exchange with y = 0: every slot is rewritten every step
             // ---- y_j = tau * A22[:, j] . v for my columns j > k: 32 lanes per column, SYTRD_CB columns per pass
             {
-                const int seg = tid & 31, ce = tid >> 5;
-                for (int cb = c0; cb < nc; cb += SYTRD_CB) {
+                const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;      // cpp columns per pass
+                for (int cb = c0; cb < nc; cb += cpp) {
                     const bool have = cb + ce < nc;
                     const double *col = slab + (size_t)(have ? cb + ce : c0) * n + (k + 1);
                     double s0 = 0.0, s1 = 0.0;
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             // ---- while y travels: Q <- Q H_k on my rows of Q (needs only v_k; same lanes own the same
             //      elements in every step, so no barrier).  Replaces the ormtr back-transformation by one GEMM.
             if (Qout) {
-                const int seg = tid & 31, ce = tid >> 5;
-                for (int rb = 0; rb < nc; rb += SYTRD_CB) {
+                const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;
+                for (int rb = 0; rb < nc; rb += cpp) {
                     const bool have = rb + ce < nc;
                     double *q = qrow + (size_t)(have ? rb + ce : 0) * n + (k + 1);
                     double s0 = 0.0, s1 = 0.0;
@@ -333,6 +338,8 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             SYTRD_TICK(4);                                // Q accumulation
 
             // ---- everyone: full y -> LDS, y.v, w = y - (tau/2)(y.v) v
+            if (!next_owner)
+                for (int z = 0; z < lazy; ++z) __builtin_amdgcn_s_sleep(8);
             for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(yb, i0, nthr, m, tag, ws, err);   // ws = y for now
             double bad = ok ? 0.0 : 1.0, dot = 0.0;
             if (ok)
@@ -375,11 +382,6 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
                         if (e < ne) base[(size_t)e * n + i] -= vi * wj[e] + wi * vj[e];
                 }
             }
-        } else if (next_owner) {
-            double *col = slab + (size_t)c0 * n + (k + 1);
-            double part = 0.0;
-            for (int i = 2 + tid; i < m; i += nthr) part += col[i] * col[i];
-            reflector(k + 1, block_sum(part, red, rs));
         }
         __syncthreads();
         SYTRD_TICK(3);                                    // rank-2 update (+ reflector when next owner)

@@ -5,6 +5,9 @@
 #include <cmath>
 #include <vector>
 using namespace jcdf;
+#ifndef JCDF_SYTRD_PROFILE
+__device__ u64 g_sytrd_prof[8];
+#endif
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 510;
@@ -19,6 +22,8 @@ int main(int argc, char **argv)
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dD, n * 8); hipMalloc(&dE, n * 8); hipMalloc(&dT, n * 8); hipMalloc(&w, wb);
     const int ncol = (n + G - 1) / G;
     const bool withq = argc > 3 ? atoi(argv[3]) != 0 : true;
+    const int lazy = argc > 4 ? atoi(argv[4]) : 0;
+    const int nthr = argc > 5 ? atoi(argv[5]) : 256;
     const size_t lds = ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
     double *dQ; hipMalloc(&dQ, A.size() * 8);
     hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -29,8 +34,8 @@ int main(int argc, char **argv)
         hipMemcpyToSymbol(HIP_SYMBOL(g_sytrd_prof), zero, sizeof(zero));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(256), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                           (u64 *)(w + 64) + 4 * (n + 1), (int *)(w + 8), withq ? dQ : nullptr);
+        hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
+                           (u64 *)(w + 64) + 2 * (n + 1), (int *)(w + 8), withq ? dQ : nullptr, lazy);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         u64 p[8]; hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sytrd_prof), sizeof(p));
@@ -41,7 +46,7 @@ int main(int argc, char **argv)
         for (int i = 0; i < n; ++i) { tr += A[(size_t)i * n + i]; trT += d[i]; frT += d[i] * d[i] + (i < n - 1 ? 2 * e[i] * e[i] : 0); }
         for (size_t i = 0; i < A.size(); ++i) fr += A[i] * A[i];
         printf("   invariants: trace %.3e  frob^2 rel %.3e\n", tr - trT, (fr - frT) / fr);
-        printf("n=%d G=%d lds=%zu: %.3f ms (%.2f us/col) err=%d | per column us: wait_v %.2f  y %.2f  Q %.2f  wait_y %.2f  update %.2f\n", n, G, lds, ms,
+        printf("n=%d G=%d T=%d lds=%zu: %.3f ms (%.2f us/col) err=%d | per column us: wait_v %.2f  y %.2f  Q %.2f  wait_y %.2f  update %.2f\n", n, G, nthr, lds, ms,
                1e3 * ms / n, err, p[0] / 100.0 / n, p[1] / 100.0 / n, p[4] / 100.0 / n, p[2] / 100.0 / n, p[3] / 100.0 / n);
     }
     if (withq) {          // Q^T A Q == T and Q^T Q == I
