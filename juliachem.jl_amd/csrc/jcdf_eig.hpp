@@ -88,25 +88,29 @@ __device__ __forceinline__ bool sub(const u64 *g, int idx, unsigned tag, double 
 
 // Batched form: elements idx = first + e*stride (e < 8, idx < count) are requested together, so a
 // thread pays one memory round trip for all of them instead of one per element.
-__device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int count, unsigned tag, double *dst, int *err)
+// `beat` (optional): one more word polled in the same round trips, only its tag (`btag`) matters.
+__device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int count, unsigned tag, double *dst, int *err,
+                                     const u64 *beat = nullptr, unsigned btag = 0)
 {
-    unsigned pending = 0;
+    unsigned pending = beat ? 1u << 8 : 0u;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         if (first + e * stride < count) pending |= 1u << e;
     unsigned spins = 0;
     u64 t0 = 0;
     while (pending) {
-        u64 a[8];
+        u64 a[8], b = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (pending & (1u << e)) a[e] = __hip_atomic_load(g + first + e * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pending & (1u << 8)) b = __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if ((pending & (1u << e)) && (unsigned)(a[e] & 3ULL) == tag) {
                 dst[first + e * stride] = __longlong_as_double((long long)(a[e] & ~3ULL));
                 pending &= ~(1u << e);
             }
+        if ((pending & (1u << 8)) && (unsigned)(b & 3ULL) == btag) pending &= ~(1u << 8);
         if (!pending) break;
         if (!spin_ok(spins, t0, err)) return false;
     }
@@ -196,10 +200,8 @@ __device__ __forceinline__ bool block_all(bool ok, double *red, unsigned &rs)
 constexpr int SYTRD_CB = 8;      // local columns processed together (independent accumulators)
 
 // A: n x n symmetric (full storage, lda >= n).  Workspace: `err` word + granule buffers
-//   vg: 2 x (n+1) granules (slot n of a half carries tau), yg: 2 x n,
-// all zeroed before launch.  `lazy`: s_sleep units a workgroup that does NOT own the next column
-// waits before it starts polling y (only the next owner is on the critical path; fewer polls on the
-// fabric shorten its hop).
+//   vg: 2 x (n+1) granules (slot n of a half carries tau), yg: 2 x n, hg: 2 x gridDim.x (heartbeats),
+// all zeroed before launch.
 // LDS: ((Qout ? 2 : 1) * ncol_max * n + 2 n + 32) doubles, ncol_max = ceil(n / gridDim.x).
 // Qout (optional, n x n row-major): the orthogonal matrix Q = H_0 H_1 ... H_{n-3} of A = Q T Q^T,
 // accumulated on the fly (rows distributed like the columns of A), so eigenvectors of A are Q Z.
@@ -209,16 +211,22 @@ constexpr int SYTRD_CB = 8;      // local columns processed together (independen
 // (redundantly, no exchange), w, rank-2 update of its own columns; the owner of column k+1 updates that column FIRST
 // (the norm of the new reflector is accumulated in the same pass) and publishes v_{k+1} before it
 // updates the rest.
-// Buffer reuse (parity of k) is safe without barriers: v_{k+2} can only be formed after every
-// workgroup has published y_{k+1}, i.e. after it has consumed v_{k+1}, v_k and y_k.
+// Buffer reuse (parity of k) is safe without barriers: whoever publishes an item (k+1) has taken y_k, and
+// a workgroup publishes y_k only after it has consumed v_k and every item (k-1).  A workgroup whose
+// columns are all finished publishes no y any more but still needs every later reflector for its rows
+// of Q and must not be overrun: from then on it publishes a heartbeat (k) instead, and the others take
+// its heartbeat (k-1) together with y_k (one step old when asked for, so it costs no waiting, and only
+// the last ~gridDim.x steps have such workgroups at all).
 __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     u64 *vg, u64 *yg, int *err, double *__restrict__ Qout, int lazy)
+                                                     u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int ncol_max = (n + G - 1) / G;
     const int nc = (n - g + G - 1) / G > 0 ? (n - g + G - 1) / G : 0;       // my columns: g, g+G, ...
+    const int Ga = n < G ? n : G;                         // workgroups that own columns and take part
+    if (nc == 0) return;                                  // owns nothing; nobody waits for it
     double *slab = lds;                                   // column c (global j = g + c G) at slab + c*n
     double *vs = lds + (size_t)ncol_max * n;
     double *ws = vs + n;
@@ -338,14 +346,17 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             SYTRD_TICK(4);                                // Q accumulation
 
             // ---- everyone: full y -> LDS, y.v, w = y - (tau/2)(y.v) v
-            if (!next_owner)
-                for (int z = 0; z < lazy; ++z) __builtin_amdgcn_s_sleep(8);
-            for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(yb, i0, nthr, m, tag, ws, err);   // ws = y for now
+            for (int i0 = tid, first = 1; (i0 < m || first) && ok; i0 += 8 * nthr, first = 0)        // ws = y for now
+                ok = sub8(yb, i0, nthr, m, tag, ws, err,
+                          (first && k >= 1 && tid < Ga && tid + ((n - 1 - tid) / G) * G <= k)    // workgroup `tid` has no column > k
+                              ? hg + (size_t)((k - 1) & 1) * G + tid : nullptr, step_tag(k - 1));
             double bad = ok ? 0.0 : 1.0, dot = 0.0;
             if (ok)
                 for (int i = tid; i < m; i += nthr) dot += ws[i] * vs[i];   // each thread re-reads only what it wrote
             block_sum2(bad, dot, red, rs);
             if (bad != 0.0) return;
+            if (tid == 0 && g + (nc - 1) * G <= k + 1)                      // from the step before my last y on:
+                pub(hg + (size_t)(k & 1) * G, g, 0.0, tag);                 // heartbeat "v_k and y_k are behind me"
             SYTRD_TICK(2);                                // waited for y
             const double al = -0.5 * tau * dot;
             for (int i = tid; i < m; i += nthr) ws[i] += al * vs[i];

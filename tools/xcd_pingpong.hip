@@ -38,7 +38,9 @@ __global__ void pingpong(u64 *flag, int a, int b, int rounds, u64 *out, int nele
 
 // all-gather: G participating blocks (those with blockIdx % stride == 0), each publishes `per` granules per round and
 // reads all G*per; rounds back to back.  out[0] = ticks
-__global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 *out)
+// interleave != 0: granule i of a workgroup lives at slot i*G + g (neighbouring slots belong to different
+// workgroups, as when slot == matrix column and columns are dealt out cyclically) instead of g*per + i
+__global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 *out, int interleave)
 {
     if (blockIdx.x % stride != 0) return;
     const int g = blockIdx.x / stride;
@@ -48,7 +50,7 @@ __global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 
     for (int r = 1; r <= rounds; ++r) {
         u64 *b = buf + (size_t)(r & 1) * total;
         for (int i = tid; i < per; i += blockDim.x)
-            __hip_atomic_store(b + g * per + i, (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(b + (interleave ? i * G + g : g * per + i), (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < total; i += blockDim.x)
             SPIN_UNTIL(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u64)r);
         __syncthreads();
@@ -75,15 +77,16 @@ int main()
             printf("pingpong nelem=%3d %-30s xcc %llu/%llu : %.3f us per hop\n", nelem, c.what, h[1], h[2],
                    (double)h[0] / 100.0 / (2.0 * rounds));
         }
-    struct { int G, stride, per; } ag[] = {{16, 8, 32}, {16, 1, 32}, {32, 8, 16}, {64, 1, 8}, {64, 4, 8}, {8, 8, 64}, {8, 1, 64}, {16, 8, 64}, {64, 1, 16}};
+    struct { int G, stride, per; } ag[] = {{16, 8, 32}, {16, 1, 32}, {32, 8, 16}, {64, 1, 8}, {64, 4, 8}, {8, 8, 64}, {8, 1, 64}, {16, 8, 64}, {64, 1, 16}, {5, 1, 8}, {64, 1, 1}};
+    for (int il = 0; il < 2; ++il)
     for (auto &c : ag) {
         hipMemset(flag, 0, 1 << 20);
         hipMemset(out, 0, 64);
-        hipLaunchKernelGGL(allgather, dim3(c.G * c.stride), dim3(256), 0, 0, flag, c.G, c.stride, c.per, rounds, out);
+        hipLaunchKernelGGL(allgather, dim3(c.G * c.stride), dim3(256), 0, 0, flag, c.G, c.stride, c.per, rounds, out, il);
         hipDeviceSynchronize();
         u64 h[1];
         hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
-        printf("allgather G=%2d stride=%d (%s) %3d granules each (%d total): %.3f us per round\n", c.G, c.stride,
+        printf("allgather %s G=%2d stride=%d (%s) %3d granules each (%d total): %.3f us per round\n", il ? "interleaved" : "contiguous ", c.G, c.stride,
                c.stride % 8 == 0 ? "one XCD" : "spread", c.per, c.G * c.per, (double)h[0] / 100.0 / rounds);
     }
     return 0;
