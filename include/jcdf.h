@@ -194,6 +194,14 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* Second stage of the same eigensolve: all eigenvalues and eigenvectors of the symmetric tridiagonal
+ * matrix (d_D diagonal, d_E sub-diagonal, both device, length n and n-1) by divide & conquer
+ * (LAPACK dstedc 'I' semantics; csrc/jcdf_dc.hpp).  On return (stream-ordered) d_D holds the eigenvalues
+ * ascending and d_Z (n x n column-major, leading dimension ldz) the eigenvectors in its columns; d_E is
+ * unchanged.  d_work: jcdf_stedc_workspace_bytes(n) bytes of device memory. */
+int64_t jcdf_stedc_workspace_bytes(int64_t n);
+int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, double *d_Z, int64_t ldz,
+                          void *d_work, int64_t work_bytes);
 
 
 /* ---- introspection ------------------------------------------------------------ */

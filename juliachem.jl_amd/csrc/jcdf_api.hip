@@ -8,12 +8,15 @@
 #include "jcdf_host_lapack.hpp"
 #include "jcdf_eig.hpp"
 #include "jcdf_chol.hpp"
+#include "jcdf_dc.hpp"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -432,6 +435,98 @@ int32_t upload_linv_from_device(jcdf_handle *h, const CholBuffers &w)
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_metric = true;
     return JCDF_OK;
+}
+
+// ---- divide & conquer plan (static per n): the merges of every level, bottom-up pairing ------------------
+struct DcLevel {
+    int nm = 0, maxm = 0, has_carry = 0;
+    int64_t rows = 0;                // packed rows used by this level
+    size_t merge_off = 0;            // index of this level's first DcMerge in the device array
+};
+struct DcPlan {
+    std::vector<DcLevel> levels;
+    DcMerge *d_merges = nullptr;
+    int64_t max_rows = 0;
+    int max_nm = 0;
+};
+std::mutex g_dc_mutex;
+std::map<std::pair<int, int64_t>, DcPlan> g_dc_plans;       // (device, n)
+
+const DcPlan *dc_plan(int64_t n)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_dc_mutex);
+    auto it = g_dc_plans.find({dev, n});
+    if (it != g_dc_plans.end()) return &it->second;
+    DcPlan plan;
+    std::vector<DcMerge> all;
+    std::vector<std::pair<int, int>> blocks;                // (start, size)
+    for (int i = 0; i < (int)n; ++i) blocks.push_back({i, 1});
+    while (blocks.size() > 1) {
+        DcLevel lv;
+        lv.merge_off = all.size();
+        std::vector<std::pair<int, int>> next;
+        int64_t rows = 0;
+        for (size_t b = 0; b + 1 < blocks.size(); b += 2) {
+            DcMerge mg{blocks[b].first, blocks[b].second, blocks[b + 1].second, (int)rows};
+            const int m = mg.n1 + mg.n2;
+            rows += roundup(m, 16);
+            all.push_back(mg);
+            lv.nm++;
+            lv.maxm = std::max(lv.maxm, m);
+            next.push_back({mg.s, m});
+        }
+        if (blocks.size() % 2) {                                // odd block out: carried to the next level unchanged;
+            lv.has_carry = 1;                                   // its descriptor sits behind the level's merges
+            all.push_back(DcMerge{blocks.back().first, blocks.back().second, 0, 0});
+            next.push_back(blocks.back());
+        }
+        lv.rows = rows;
+        plan.max_rows = std::max(plan.max_rows, rows);
+        plan.max_nm = std::max(plan.max_nm, lv.nm);
+        plan.levels.push_back(lv);
+        blocks.swap(next);
+    }
+    if (!all.empty()) {
+        if (hipMalloc((void **)&plan.d_merges, all.size() * sizeof(DcMerge)) != hipSuccess) return nullptr;
+        if (hipMemcpy(plan.d_merges, all.data(), all.size() * sizeof(DcMerge), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    }
+    auto res = g_dc_plans.emplace(std::make_pair(dev, n), std::move(plan));
+    return &res.first->second;
+}
+
+struct DcWork {                      // carve-up of the caller's workspace
+    double *w2, *Zb, *X, *Zp, *G, *dl, *zl, *zhat, *mu, *defval, *rho;
+    int *col, *defcol, *org, *K;
+    int64_t ldx, ldzb;
+    int64_t bytes;
+};
+DcWork dc_carve(char *base, int64_t n, const DcPlan *plan)
+{
+    DcWork wk{};
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+    const int64_t rows = plan->max_rows + 16;
+    wk.ldx = roundup(n, 64) + 64;
+    wk.ldzb = n;
+    wk.w2 = (double *)take(n * 8);
+    wk.Zb = (double *)take(n * n * 8);
+    wk.X = (double *)take(rows * wk.ldx * 8);
+    wk.Zp = (double *)take(rows * wk.ldx * 8);
+    wk.G = (double *)take(rows * wk.ldx * 8);
+    wk.dl = (double *)take(rows * 8);
+    wk.zl = (double *)take(rows * 8);
+    wk.zhat = (double *)take(rows * 8);
+    wk.mu = (double *)take(rows * 8);
+    wk.defval = (double *)take(rows * 8);
+    wk.rho = (double *)take((plan->max_nm + 1) * 8);
+    wk.col = (int *)take(rows * 4);
+    wk.defcol = (int *)take(rows * 4);
+    wk.org = (int *)take(rows * 4);
+    wk.K = (int *)take((plan->max_nm + 1) * 4);
+    wk.bytes = off;
+    return wk;
 }
 
 }  // namespace
@@ -947,6 +1042,72 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
     int64_t n = 64;
     while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;
     return n;
+}
+
+int64_t jcdf_stedc_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    const DcPlan *plan = dc_plan(n);
+    if (!plan) return -1;
+    return dc_carve(nullptr, n, plan).bytes;
+}
+
+int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, double *d_Z, int64_t ldz, void *d_work,
+                          int64_t work_bytes)
+{
+    if (n <= 0 || !d_D || !d_Z || ldz < n || (n > 1 && !d_E) || !d_work) return JCDF_ERR_INVALID;
+    const DcPlan *plan = dc_plan(n);
+    if (!plan) return JCDF_ERR_ALLOC;
+    DcWork wk = dc_carve((char *)d_work, n, plan);
+    if (work_bytes < wk.bytes) return JCDF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_dc_update_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, DcCfg::SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_dc_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    const int L = (int)plan->levels.size();
+    // ping-pong so that the last level writes into the caller's buffers: eigenvalues end in d_D, vectors in d_Z
+    double *Za = (L % 2 == 0) ? d_Z : wk.Zb, *Zn = (L % 2 == 0) ? wk.Zb : d_Z;
+    int64_t lda = (L % 2 == 0) ? ldz : wk.ldzb, ldn = (L % 2 == 0) ? wk.ldzb : ldz;
+    double *wa = (L % 2 == 0) ? d_D : wk.w2, *wn = (L % 2 == 0) ? wk.w2 : d_D;
+    // (wa may be d_D itself: k_dc_init reads and writes only its own diagonal element per thread)
+    hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_D, d_E, (int)n, wa, Za, lda, Zn, ldn);
+    for (int l = 0; l < L; ++l) {
+        const DcLevel &lv = plan->levels[l];
+        const DcMerge *mg = plan->d_merges + lv.merge_off;
+        const int maxm = lv.maxm;
+        const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)2 * maxm * 4;
+        if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
+        hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
+                           wk.dl, wk.zl, wk.col, wk.defcol, wk.defval);
+        const unsigned gx = (unsigned)std::max(1, (maxm + 31) / 32);          // 32 roots (8 lanes each) per block
+        hipLaunchKernelGGL(k_dc_secular<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org,
+                           wk.mu);
+        hipLaunchKernelGGL(k_dc_zhat<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu,
+                           wk.zhat);
+        hipLaunchKernelGGL(k_dc_vectors<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat,
+                           wk.col, Za, lda, wk.X, wk.Zp, wk.ldx);
+        if (maxm >= 96) {
+            const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
+            hipLaunchKernelGGL(k_dc_update_mfma, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
+                               wk.X, wk.Zp, wk.ldx, wk.G);
+        } else {
+            const unsigned tiles = (unsigned)std::min(64, ((maxm + 15) / 16) * ((maxm + 15) / 16));
+            hipLaunchKernelGGL(k_dc_update_simple, dim3(tiles, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.X, wk.Zp, wk.ldx,
+                               wk.G);
+        }
+        const unsigned fx = (unsigned)std::max(1, (maxm + 7) / 8);
+        hipLaunchKernelGGL(k_dc_finish, dim3(fx, (unsigned)lv.nm), dim3(256), (size_t)maxm * 8, st, mg, wk.K, wk.dl, wk.org, wk.mu,
+                           wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn);
+        if (lv.has_carry)
+            hipLaunchKernelGGL(k_dc_carry, dim3(16, 1), dim3(256), 0, st, mg + lv.nm, Za, lda, Zn, ldn, wa, wn);
+        std::swap(Za, Zn);
+        std::swap(lda, ldn);
+        std::swap(wa, wn);
+    }
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }

@@ -1,0 +1,429 @@
+// jcdf_dc.hpp — divide & conquer eigensolver for a symmetric tridiagonal matrix on the device
+// (caller side of the hot path, SURVEY 8 row f1: second stage of the replicated eigensolve of the
+// SCF iteration, /root/reference/src/rhf/energy/SCF.jl:1080-1083, after k_sytrd_lower).
+//
+// Why: rocSOLVER's stedc needs 2.6 ms at N = 510, 1.7 ms of it in five launches of a merge kernel that
+// solves the secular equations with little parallelism (profiles/r01_kernel_stats_bench.txt).  The
+// algorithm here is the classical one (Cuppen; Gu & Eisenstat; LAPACK dstedc/dlaed1-4), organised for
+// the GPU: the matrix is torn down to 1 x 1 leaves, and every level of the tree is a handful of launches
+// over ALL merges of that level:
+//   prepare : z = [last row of Q1, +-first row of Q2]/sqrt(2), rho = 2|beta|, merge-sort of the poles,
+//             deflation (negligible z_i; close poles rotated together), one workgroup per merge
+//   secular : every root of 1 + rho sum z_i^2/(d_i - x) by the "middle way" rational iteration inside a
+//             shrinking bracket, relative to the nearer pole (so d_i - lambda_j is accurate), 8 lanes/root
+//   zhat    : Loewner formula for the z that makes the computed roots exact (orthogonality of the vectors)
+//   vectors : X[i][j] = zhat_i/(d_i - lambda_j), normalised; gather of the non-deflated columns of Q
+//   update  : Q_new = Q_gathered X  (the O(n^3) part; fp64 MFMA for the large merges)
+//   finish  : deflated columns copied, everything sorted ascending
+// Eigenvectors are column-major (column j = eigenvector j), eigenvalues ascending, like LAPACK.
+#pragma once
+#include "jcdf_gemm.hpp"
+
+namespace jcdf {
+
+struct DcMerge {          // one merge of the tree: rows/columns [s, s + n1 + n2) of the matrix
+    int s, n1, n2;
+    int xoff;             // first row of this merge in the packed work matrices (multiple of 16)
+};
+
+constexpr double DC_EPS = 1.1102230246251565e-16;      // unit roundoff (LAPACK dlamch('E'))
+
+// ---- level 0: tear the matrix into 1 x 1 leaves -------------------------------------------------------
+// w[i] = d[i] - |e[i-1]| - |e[i]|  (every off-diagonal is a tear), Z = I; the second (ping-pong) buffer
+// is zeroed: every level writes only the diagonal blocks of its merges and the next level relies on the
+// blocks between two children being zero.
+__global__ void k_dc_init(const double *__restrict__ d, const double *__restrict__ e, int n, double *__restrict__ w,
+                          double *__restrict__ Z, int64_t ldz, double *__restrict__ Z2, int64_t ldz2)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) {
+        const int i = (int)idx;
+        w[i] = d[i] - (i > 0 ? fabs(e[i - 1]) : 0.0) - (i < n - 1 ? fabs(e[i]) : 0.0);
+    }
+    if (idx < (int64_t)n * n) {
+        Z[(idx / n) * ldz + idx % n] = (idx / n == idx % n) ? 1.0 : 0.0;
+        Z2[(idx / n) * ldz2 + idx % n] = 0.0;
+    }
+}
+
+// ---- prepare: one workgroup per merge ---------------------------------------------------------------------
+// In : w (eigenvalues of the two children, each ascending), Z (their eigenvectors, block diagonal), e.
+// Out (packed at xoff): K (non-deflated count), dl[K] ascending poles, zl[K], col[K] (column of Z, local
+//      index, of pole k), defcol[m-K]/defval[m-K] (deflated eigenpairs), rho.  Givens rotations of the
+//      close-pole deflation are applied to the columns of Z in place.
+// LDS: (2*m + max(m, 256)) doubles + 2*m ints.
+__global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ merges, const double *__restrict__ w,
+                                                    const double *__restrict__ e, double *__restrict__ Z, int64_t ldz,
+                                                    int *__restrict__ Kout, double *__restrict__ rho_out,
+                                                    double *__restrict__ dl, double *__restrict__ zl, int *__restrict__ col,
+                                                    int *__restrict__ defcol, double *__restrict__ defval)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const DcMerge mg = merges[blockIdx.x];
+    const int s = mg.s, n1 = mg.n1, m = mg.n1 + mg.n2, tid = threadIdx.x, nthr = blockDim.x;
+    double *dd = sm, *zz = sm + m, *red = sm + 2 * m;                        // by local column index
+    int *perm = reinterpret_cast<int *>(sm + 2 * m + (m > 256 ? m : 256));   // sorted position -> local index
+    int *klist = perm + m;
+    const double beta = e[s + n1 - 1];
+    const double sgn = beta < 0.0 ? -1.0 : 1.0;
+    const double rho = 2.0 * fabs(beta);
+    double lmax = 0.0;
+    for (int i = tid; i < m; i += nthr) {
+        const double di = w[s + i];
+        const double zi = (i < n1 ? Z[(int64_t)(s + i) * ldz + (s + n1 - 1)] : sgn * Z[(int64_t)(s + i) * ldz + (s + n1)]) * 0.70710678118654752440;
+        dd[i] = di;
+        zz[i] = zi;
+        lmax = fmax(lmax, fmax(fabs(di), fabs(zi)));
+    }
+    red[tid] = lmax;
+    __syncthreads();
+    for (int off = nthr / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    const double tol = 8.0 * DC_EPS * red[0];
+    __syncthreads();
+    // merge of the two ascending runs: rank by binary search in the other run (ties: first run first)
+    for (int i = tid; i < m; i += nthr) {
+        const double x = dd[i];
+        int lo, hi;
+        if (i < n1) { lo = n1; hi = m; while (lo < hi) { const int mid = (lo + hi) >> 1; if (dd[mid] < x) lo = mid + 1; else hi = mid; } perm[i + (lo - n1)] = i; }
+        else        { lo = 0; hi = n1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (dd[mid] <= x) lo = mid + 1; else hi = mid; } perm[(i - n1) + lo] = i; }
+    }
+    __syncthreads();
+    // deflation scan in ascending order (LAPACK dlaed2), every thread runs the scalar logic on the same
+    // LDS values; the rare rotations are applied to the two columns of Z by the whole workgroup
+    int K = 0, ndef = 0, pj = -1;
+    const int xo = mg.xoff;
+    for (int t = 0; t < m; ++t) {
+        const int j = perm[t];
+        const double zj = zz[j];
+        if (rho * fabs(zj) <= tol) {                                         // eigenpair (d_j, e_j) unchanged
+            if (tid == 0) { defcol[xo + ndef] = j; defval[xo + ndef] = dd[j]; }
+            ++ndef;
+            continue;
+        }
+        if (pj < 0) { pj = j; continue; }
+        const double zp = zz[pj], dp = dd[pj], dj = dd[j];
+        const double tau = hypot(zj, zp);
+        const double c = zj / tau, sn = -zp / tau;
+        if (fabs((dj - dp) * c * sn) <= tol) {                               // poles too close: rotate z_pj into z_j
+            __syncthreads();
+            if (tid == 0) {
+                zz[j] = tau;
+                zz[pj] = 0.0;
+                const double t1 = dp * c * c + dj * sn * sn;
+                dd[j] = dp * sn * sn + dj * c * c;
+                dd[pj] = t1;
+                defcol[xo + ndef] = pj;
+                defval[xo + ndef] = t1;
+            }
+            double *cp = Z + (int64_t)(s + pj) * ldz + s, *cj = Z + (int64_t)(s + j) * ldz + s;
+            for (int r = tid; r < m; r += nthr) {                             // drot(Q(:,pj), Q(:,j), c, s)
+                const double a = cp[r], b = cj[r];
+                cp[r] = c * a + sn * b;
+                cj[r] = c * b - sn * a;
+            }
+            __syncthreads();
+            ++ndef;
+            pj = j;
+        } else {
+            if (tid == 0) klist[K] = pj;
+            ++K;
+            pj = j;
+        }
+    }
+    if (pj >= 0) {
+        if (tid == 0) klist[K] = pj;
+        ++K;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += nthr) {
+        const int c = klist[k];
+        dl[xo + k] = dd[c];
+        zl[xo + k] = zz[c];
+        col[xo + k] = c;
+    }
+    if (tid == 0) {
+        Kout[blockIdx.x] = K;
+        rho_out[blockIdx.x] = rho;
+    }
+}
+
+// ---- secular equation ------------------------------------------------------------------------------------
+// Root j of f(x) = 1 + rho sum_i z_i^2/(d_i - x) in (d_j, d_{j+1}) (last: (d_K, d_K + rho |z|^2]),
+// returned as (origin o, mu) with lambda = d_o + mu, o the nearer pole.  LANES lanes share the sums.
+template <int LANES>
+__device__ __forceinline__ double lanes_sum(double x)
+{
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, LANES);
+    return x;
+}
+
+template <int LANES>
+__device__ void dc_secular_root(int j, int K, const double *__restrict__ d, const double *__restrict__ z, double rho,
+                                int lane, int *org_out, double *mu_out)
+{
+    // sums over the poles split at j: psi (poles <= j), phi (poles > j), and their derivatives
+    auto eval = [&](int o, double mu, double &psi, double &dpsi, double &phi, double &dphi) {
+        double a = 0.0, da = 0.0, b = 0.0, db = 0.0;
+        const double dorg = d[o];
+        for (int i = lane; i < K; i += LANES) {
+            const double t = z[i] / ((d[i] - dorg) - mu);
+            const double zt = z[i] * t;
+            if (i <= j) { a += zt; da += t * t; } else { b += zt; db += t * t; }
+        }
+        psi = rho * lanes_sum<LANES>(a);
+        dpsi = rho * lanes_sum<LANES>(da);
+        phi = rho * lanes_sum<LANES>(b);
+        dphi = rho * lanes_sum<LANES>(db);
+    };
+    int o;
+    double lo, hi;                                                            // bracket for mu: f(lo) < 0 < f(hi) (or a pole)
+    double psi, dpsi, phi, dphi;
+    if (j < K - 1) {
+        const double gap = d[j + 1] - d[j];
+        eval(j, 0.5 * gap, psi, dpsi, phi, dphi);
+        if (1.0 + psi + phi >= 0.0) { o = j; lo = 0.0; hi = 0.5 * gap; }
+        else { o = j + 1; lo = -0.5 * gap; hi = 0.0; }
+    } else {
+        double zz = 0.0;
+        for (int i = lane; i < K; i += LANES) zz += z[i] * z[i];
+        zz = lanes_sum<LANES>(zz);
+        o = j; lo = 0.0; hi = rho * zz;
+        if (!(hi > 0.0)) hi = DC_EPS * fabs(d[j]) + 1e-300;
+    }
+    double mu = 0.5 * (lo + hi);
+    const double dj = d[j] - d[o], dj1 = (j < K - 1) ? d[j + 1] - d[o] : 0.0;
+    for (int it = 0; it < 100; ++it) {
+        eval(o, mu, psi, dpsi, phi, dphi);
+        const double f = 1.0 + psi + phi;
+        const double err = 8.0 * (fabs(phi) + fabs(psi)) + 1.0 + fabs(mu) * (dpsi + dphi);   // dlaed4's erretm
+        if (fabs(f) <= DC_EPS * err) break;
+        if (f < 0.0) lo = mu; else hi = mu;
+        if (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi))) { mu = 0.5 * (lo + hi); break; }
+        // rational model: psi ~ s + a/(D1 - eta) (pole j), phi ~ t + b/(D2 - eta) (pole j+1), eta = step in mu
+        const double D1 = dj - mu, D2 = dj1 - mu;
+        double next;
+        if (j < K - 1) {
+            const double a = dpsi * D1 * D1, b = dphi * D2 * D2;
+            const double c0 = 1.0 + (psi - dpsi * D1) + (phi - dphi * D2);
+            // c0 (D1-eta)(D2-eta) + a (D2-eta) + b (D1-eta) = 0
+            const double qa = c0, qb = -(c0 * (D1 + D2) + a + b), qc = c0 * D1 * D2 + a * D2 + b * D1;
+            double eta;
+            if (qa == 0.0) eta = -qc / qb;
+            else {
+                const double disc = qb * qb - 4.0 * qa * qc;
+                const double sq = sqrt(fmax(disc, 0.0));
+                // the root between the two poles (D1 < eta < D2 in the shifted variable): stable form
+                const double q = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+                const double r1 = q / qa, r2 = (q != 0.0) ? qc / q : r1;
+                eta = (r1 > D1 && r1 < D2) ? r1 : r2;
+            }
+            next = mu + eta;
+        } else {
+            const double a = dpsi * D1 * D1, c0 = 1.0 + (psi - dpsi * D1);   // single pole below
+            next = mu + (D1 + a / c0);
+        }
+        if (!(next > lo && next < hi)) next = 0.5 * (lo + hi);               // also catches NaN
+        mu = next;
+    }
+    if (lane == 0) {
+        *org_out = o;
+        *mu_out = mu;
+    }
+}
+
+// grid: (blocks, merges); LANES lanes per root
+template <int LANES>
+__global__ __launch_bounds__(256) void k_dc_secular(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                    const double *__restrict__ rho_in, const double *__restrict__ dl,
+                                                    const double *__restrict__ zl, int *__restrict__ org,
+                                                    double *__restrict__ mu)
+{
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y];
+    const int lane = threadIdx.x % LANES;
+    const int rpb = blockDim.x / LANES;                                       // roots per block
+    for (int j = blockIdx.x * rpb + threadIdx.x / LANES; j < ((K + rpb - 1) / rpb) * rpb; j += gridDim.x * rpb) {
+        // (whole groups stay in the loop together: __shfl needs every lane of the group)
+        if (j < K) dc_secular_root<LANES>(j, K, dl + mg.xoff, zl + mg.xoff, rho_in[blockIdx.y], lane, org + mg.xoff + j, mu + mg.xoff + j);
+    }
+}
+
+// ---- zhat (Loewner / Gu-Eisenstat): the z for which the computed roots are the exact eigenvalues ----------
+// zhat_i = sign(z_i) sqrt( (lambda_i - d_i) prod_{j != i} (lambda_j - d_i)/(d_j - d_i) ),
+// with d_i - lambda_j = (d_i - d_{o_j}) - mu_j.  LANES lanes per i.
+template <int LANES>
+__global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                 const double *__restrict__ dl, const double *__restrict__ zl,
+                                                 const int *__restrict__ org, const double *__restrict__ mu,
+                                                 double *__restrict__ zhat)
+{
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y];
+    const double *d = dl + mg.xoff, *m_ = mu + mg.xoff;
+    const int *o = org + mg.xoff;
+    const int lane = threadIdx.x % LANES, rpb = blockDim.x / LANES;
+    for (int i = blockIdx.x * rpb + threadIdx.x / LANES; i < ((K + rpb - 1) / rpb) * rpb; i += gridDim.x * rpb) {
+        double p = 1.0;
+        if (i < K) {
+            const double di = d[i];
+            for (int j = lane; j < K; j += LANES) {
+                const double num = m_[j] - (di - d[o[j]]);                    // lambda_j - d_i
+                p *= (j == i) ? num : num / (d[j] - di);
+            }
+        }
+#pragma unroll
+        for (int off = LANES / 2; off > 0; off >>= 1) p *= __shfl_xor(p, off, LANES);
+        if (i < K && lane == 0) zhat[mg.xoff + i] = copysign(sqrt(fabs(p)), zl[mg.xoff + i]);
+    }
+}
+
+// ---- vectors: X[i][j] = zhat_i/(d_i - lambda_j) normalised over i (row-major K x K, leading dimension ldx,
+//      rows K .. roundup(K,16)-1 zeroed for the MFMA update), LANES lanes per column j;
+//      and the gather Zp[k][r] = Z[r][col_k] (k-major copy of the non-deflated columns, rows K.. zeroed) -------
+template <int LANES>
+__global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                    const double *__restrict__ dl, const int *__restrict__ org,
+                                                    const double *__restrict__ mu, const double *__restrict__ zhat,
+                                                    const int *__restrict__ col, const double *__restrict__ Z, int64_t ldz,
+                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx)
+{
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2, s = mg.s;
+    const int Kp = (K + 15) / 16 * 16;
+    const double *d = dl + mg.xoff, *zh = zhat + mg.xoff;
+    const int lane = threadIdx.x % LANES, rpb = blockDim.x / LANES;
+    double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
+    for (int j = blockIdx.x * rpb + threadIdx.x / LANES; j < ((Kp + rpb - 1) / rpb) * rpb; j += gridDim.x * rpb) {
+        double nrm = 0.0;
+        const double dorg = (j < K) ? d[org[mg.xoff + j]] : 0.0, muj = (j < K) ? mu[mg.xoff + j] : 0.0;
+        if (j < K)
+            for (int i = lane; i < K; i += LANES) {
+                const double t = zh[i] / ((d[i] - dorg) - muj);
+                nrm += t * t;
+            }
+#pragma unroll
+        for (int off = LANES / 2; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, LANES);
+        const double inv = (j < K) ? 1.0 / sqrt(nrm) : 0.0;
+        if (j < Kp)
+            for (int i = lane; i < Kp; i += LANES)
+                Xm[(int64_t)i * ldx + j] = (i < K && j < K) ? zh[i] / ((d[i] - dorg) - muj) * inv : 0.0;
+    }
+    // gather (independent of the above): thread-strided over (k, r)
+    const int64_t total = (int64_t)Kp * m;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / m), r = (int)(idx % m);
+        Zm[(int64_t)k * ldx + r] = (k < K) ? Z[(int64_t)(s + col[mg.xoff + k]) * ldz + s + r] : 0.0;
+    }
+}
+
+// ---- update: G[j][r] = sum_k X[k][j] * Zp[k][r]  (k-major operands; G row j = new eigenvector j over rows r) -
+// small/unaligned version: one thread per (j, r), 16 x 16 tiles through LDS.  grid: (tiles, merges)
+__global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                          const double *__restrict__ X, const double *__restrict__ Zp,
+                                                          int64_t ldx, double *__restrict__ Gm)
+{
+    __shared__ double xs[16][17], zs[16][17];
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2;
+    const int tj = (K + 15) / 16, tr = (m + 15) / 16;
+    const double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
+    double *G = Gm + (int64_t)mg.xoff * ldx;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    for (int tile = blockIdx.x; tile < tj * tr; tile += gridDim.x) {
+        const int j0 = (tile / tr) * 16, r0 = (tile % tr) * 16;
+        double acc = 0.0;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            xs[ty][tx] = (k0 + ty < K && j0 + tx < K) ? Xm[(int64_t)(k0 + ty) * ldx + j0 + tx] : 0.0;
+            zs[ty][tx] = (k0 + ty < K && r0 + tx < m) ? Zm[(int64_t)(k0 + ty) * ldx + r0 + tx] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += xs[k][ty] * zs[k][tx];
+            __syncthreads();
+        }
+        if (j0 + ty < K && r0 + tx < m) G[(int64_t)(j0 + ty) * ldx + r0 + tx] = acc;
+    }
+}
+
+// MFMA version for the large merges: 64 x 64 output tile per workgroup.  grid: (tiles, merges)
+using DcCfg = GemmCfg<2, 2, 2, 2, 16>;
+__global__ __launch_bounds__(256) void k_dc_update_mfma(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                        const double *__restrict__ X, const double *__restrict__ Zp,
+                                                        int64_t ldx, double *__restrict__ Gm)
+{
+    using Cfg = DcCfg;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2;
+    const int tj = (K + 63) / 64, tr = (m + 63) / 64;
+    const double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
+    double *G = Gm + (int64_t)mg.xoff * ldx;
+    for (int tile = blockIdx.x; tile < tj * tr; tile += gridDim.x) {
+        const int j0 = (tile / tr) * 64, r0 = (tile % tr) * 64;
+        double4_t acc[Cfg::WM][Cfg::WN];
+#pragma unroll
+        for (int a = 0; a < Cfg::WM; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::WN; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+        gemm_tn_core<Cfg, false>(Xm + j0, ldx, Zm + r0, ldx, (K + 15) / 16, acc, smem);
+#pragma unroll
+        for (int a = 0; a < Cfg::WM; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::WN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jj = j0 + tile_row<Cfg>(a, q), rr = r0 + tile_col<Cfg>(b);
+                    if (jj < K && rr < m) G[(int64_t)jj * ldx + rr] = acc[a][b][q];
+                }
+        __syncthreads();
+    }
+}
+
+// ---- finish: the m eigenpairs of the merged block (K new ones from G, m-K deflated ones from Z) sorted
+//      ascending into Znew / wnew.  grid: (blocks, merges); each block ranks and copies a slice of the pairs --
+__global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                   const double *__restrict__ dl, const int *__restrict__ org,
+                                                   const double *__restrict__ mu, const int *__restrict__ defcol,
+                                                   const double *__restrict__ defval, const double *__restrict__ Gm,
+                                                   int64_t ldx, const double *__restrict__ Z, int64_t ldz_in,
+                                                   double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew)
+{
+    extern __shared__ __attribute__((aligned(16))) double vals[];            // m values: new roots then deflated
+    const DcMerge mg = merges[blockIdx.y];
+    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2, s = mg.s, xo = mg.xoff;
+    for (int a = threadIdx.x; a < m; a += blockDim.x)
+        vals[a] = (a < K) ? dl[xo + org[xo + a]] + mu[xo + a] : defval[xo + a - K];
+    __syncthreads();
+    const int per = (m + gridDim.x - 1) / gridDim.x;
+    const int a0 = blockIdx.x * per, a1 = min(m, a0 + per);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int a = a0 + wave; a < a1; a += nw) {                                // one wave per eigenpair
+        const double x = vals[a];
+        int rank = 0;
+        for (int b = lane; b < m; b += 64) rank += (vals[b] < x || (vals[b] == x && b < a)) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
+        const double *src = (a < K) ? Gm + (int64_t)(xo + a) * ldx : Z + (int64_t)(s + defcol[xo + a - K]) * ldz_in + s;
+        double *dst = Znew + (int64_t)(s + rank) * ldz + s;
+        for (int r = lane; r < m; r += 64) dst[r] = src[r];
+        if (lane == 0) wnew[s + rank] = x;
+    }
+}
+
+// rows/columns of blocks that are not merged at this level (odd leaf carried up) are copied unchanged
+__global__ void k_dc_carry(const DcMerge *__restrict__ carry, const double *__restrict__ Z, int64_t ldz_in,
+                           double *__restrict__ Znew, int64_t ldz, const double *__restrict__ w, double *__restrict__ wnew)
+{
+    const DcMerge c = carry[blockIdx.y];
+    const int m = c.n1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)m * m; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int jc = (int)(idx / m), r = (int)(idx % m);
+        Znew[(int64_t)(c.s + jc) * ldz + c.s + r] = Z[(int64_t)(c.s + jc) * ldz_in + c.s + r];
+        if (r == 0) wnew[c.s + jc] = w[c.s + jc];
+    }
+}
+
+}  // namespace jcdf
