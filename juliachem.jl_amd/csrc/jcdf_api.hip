@@ -497,7 +497,7 @@ const DcPlan *dc_plan(int64_t n)
 }
 
 struct DcWork {                      // carve-up of the caller's workspace
-    double *w2, *Zb, *X, *Zp, *G, *dl, *zl, *zhat, *mu, *defval, *rho;
+    double *w2, *Zb, *X, *Zp, *G, *dl, *zl, *zhat, *mu, *defval, *rho, *sc;
     int *col, *defcol, *org, *K;
     int64_t ldx, ldzb;
     int64_t bytes;
@@ -521,6 +521,7 @@ DcWork dc_carve(char *base, int64_t n, const DcPlan *plan)
     wk.mu = (double *)take(rows * 8);
     wk.defval = (double *)take(rows * 8);
     wk.rho = (double *)take((plan->max_nm + 1) * 8);
+    wk.sc = (double *)take(16);
     wk.col = (int *)take(rows * 4);
     wk.defcol = (int *)take(rows * 4);
     wk.org = (int *)take(rows * 4);
@@ -1073,7 +1074,10 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
     int64_t lda = (L % 2 == 0) ? ldz : wk.ldzb, ldn = (L % 2 == 0) ? wk.ldzb : ldz;
     double *wa = (L % 2 == 0) ? d_D : wk.w2, *wn = (L % 2 == 0) ? wk.w2 : d_D;
     // (wa may be d_D itself: k_dc_init reads and writes only its own diagonal element per thread)
-    hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_D, d_E, (int)n, wa, Za, lda, Zn, ldn);
+    hipLaunchKernelGGL(k_dc_norm, dim3(1), dim3(256), 0, st, d_D, d_E, (int)n, wk.sc);
+    hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_D, d_E, (int)n, wa, Za, lda, Zn, ldn,
+                       wk.sc);
+    if (L == 0) hipLaunchKernelGGL(k_dc_unscale1, dim3(1), dim3(1), 0, st, wa, wk.sc);
     for (int l = 0; l < L; ++l) {
         const DcLevel &lv = plan->levels[l];
         const DcMerge *mg = plan->d_merges + lv.merge_off;
@@ -1081,7 +1085,7 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)2 * maxm * 4;
         if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
         hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
-                           wk.dl, wk.zl, wk.col, wk.defcol, wk.defval);
+                           wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc);
         const unsigned gx = (unsigned)std::max(1, (maxm + 31) / 32);          // 32 roots (8 lanes each) per block
         hipLaunchKernelGGL(k_dc_secular<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org,
                            wk.mu);
@@ -1100,7 +1104,7 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         }
         const unsigned fx = (unsigned)std::max(1, (maxm + 7) / 8);
         hipLaunchKernelGGL(k_dc_finish, dim3(fx, (unsigned)lv.nm), dim3(256), (size_t)maxm * 8, st, mg, wk.K, wk.dl, wk.org, wk.mu,
-                           wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn);
+                           wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn, wk.sc, l == L - 1 ? 1 : 0);
         if (lv.has_carry)
             hipLaunchKernelGGL(k_dc_carry, dim3(16, 1), dim3(256), 0, st, mg + lv.nm, Za, lda, Zn, ldn, wa, wn);
         std::swap(Za, Zn);

@@ -28,23 +28,47 @@ struct DcMerge {          // one merge of the tree: rows/columns [s, s + n1 + n2
 
 constexpr double DC_EPS = 1.1102230246251565e-16;      // unit roundoff (LAPACK dlamch('E'))
 
+// ---- scaling (LAPACK dstedc scales to unit max-norm: the tolerances and products below assume O(1) data) --
+// sc[0] = max(|d|, |e|) (1 for the zero matrix), sc[1] = 1/sc[0].  One workgroup.
+__global__ __launch_bounds__(256) void k_dc_norm(const double *__restrict__ d, const double *__restrict__ e, int n,
+                                                 double *__restrict__ sc)
+{
+    __shared__ double red[256];
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmax(mx, fmax(fabs(d[i]), i < n - 1 ? fabs(e[i]) : 0.0));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nrm = (red[0] > 0.0 && red[0] < 1.0e300) ? red[0] : 1.0;
+        sc[0] = nrm;
+        sc[1] = 1.0 / nrm;
+    }
+}
+
 // ---- level 0: tear the matrix into 1 x 1 leaves -------------------------------------------------------
 // w[i] = d[i] - |e[i-1]| - |e[i]|  (every off-diagonal is a tear), Z = I; the second (ping-pong) buffer
 // is zeroed: every level writes only the diagonal blocks of its merges and the next level relies on the
 // blocks between two children being zero.
 __global__ void k_dc_init(const double *__restrict__ d, const double *__restrict__ e, int n, double *__restrict__ w,
-                          double *__restrict__ Z, int64_t ldz, double *__restrict__ Z2, int64_t ldz2)
+                          double *__restrict__ Z, int64_t ldz, double *__restrict__ Z2, int64_t ldz2,
+                          const double *__restrict__ sc)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) {
         const int i = (int)idx;
-        w[i] = d[i] - (i > 0 ? fabs(e[i - 1]) : 0.0) - (i < n - 1 ? fabs(e[i]) : 0.0);
+        w[i] = (d[i] - (i > 0 ? fabs(e[i - 1]) : 0.0) - (i < n - 1 ? fabs(e[i]) : 0.0)) * sc[1];
     }
     if (idx < (int64_t)n * n) {
         Z[(idx / n) * ldz + idx % n] = (idx / n == idx % n) ? 1.0 : 0.0;
         Z2[(idx / n) * ldz2 + idx % n] = 0.0;
     }
 }
+
+__global__ void k_dc_unscale1(double *__restrict__ w, const double *__restrict__ sc) { w[0] *= sc[0]; }   // n == 1
 
 // ---- prepare: one workgroup per merge ---------------------------------------------------------------------
 // In : w (eigenvalues of the two children, each ascending), Z (their eigenvectors, block diagonal), e.
@@ -56,7 +80,8 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
                                                     const double *__restrict__ e, double *__restrict__ Z, int64_t ldz,
                                                     int *__restrict__ Kout, double *__restrict__ rho_out,
                                                     double *__restrict__ dl, double *__restrict__ zl, int *__restrict__ col,
-                                                    int *__restrict__ defcol, double *__restrict__ defval)
+                                                    int *__restrict__ defcol, double *__restrict__ defval,
+                                                    const double *__restrict__ sc)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const DcMerge mg = merges[blockIdx.x];
@@ -64,7 +89,7 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
     double *dd = sm, *zz = sm + m, *red = sm + 2 * m;                        // by local column index
     int *perm = reinterpret_cast<int *>(sm + 2 * m + (m > 256 ? m : 256));   // sorted position -> local index
     int *klist = perm + m;
-    const double beta = e[s + n1 - 1];
+    const double beta = e[s + n1 - 1] * sc[1];
     const double sgn = beta < 0.0 ? -1.0 : 1.0;
     const double rho = 2.0 * fabs(beta);
     double lmax = 0.0;
@@ -389,7 +414,8 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
                                                    const double *__restrict__ mu, const int *__restrict__ defcol,
                                                    const double *__restrict__ defval, const double *__restrict__ Gm,
                                                    int64_t ldx, const double *__restrict__ Z, int64_t ldz_in,
-                                                   double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew)
+                                                   double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew,
+                                                   const double *__restrict__ sc, int last)
 {
     extern __shared__ __attribute__((aligned(16))) double vals[];            // m values: new roots then deflated
     const DcMerge mg = merges[blockIdx.y];
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
         const double *src = (a < K) ? Gm + (int64_t)(xo + a) * ldx : Z + (int64_t)(s + defcol[xo + a - K]) * ldz_in + s;
         double *dst = Znew + (int64_t)(s + rank) * ldz + s;
         for (int r = lane; r < m; r += 64) dst[r] = src[r];
-        if (lane == 0) wnew[s + rank] = x;
+        if (lane == 0) wnew[s + rank] = last ? x * sc[0] : x;                 // the last level undoes the scaling
     }
 }
 

@@ -5,10 +5,12 @@ rocSOLVER's syevd needs ~4000 tiny launches for the tridiagonalisation (9 of its
 N = 510).  Here the tridiagonalisation is ONE persistent kernel of libjcdf_hip.so
 (`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp) which also accumulates the orthogonal factor Q while
 its reflectors travel between workgroups (A = Q T Q^T), so the back-transformation is one GEMM
-Q Z instead of LAPACK's ormtr (~30 launches, 1.1 ms).  Only stedc (divide & conquer on the
-tridiagonal matrix) still uses the vendor library already in the process (PyTorch's librocsolver).
-Matrices too large for Q to stay in LDS use ormtr.  Falls back to torch.linalg.eigh when the vendor
-entry points are unavailable or an in-kernel hand-off reports a timeout.
+Q Z instead of LAPACK's ormtr (~30 launches, 1.1 ms).  The tridiagonal eigenproblem is solved by
+the library's own divide & conquer (`jcdf_stedc_device`, csrc/jcdf_dc.hpp: 1.0 ms at N = 510 where
+rocSOLVER's stedc takes 2.6 ms).  JCDF_EIGH_VENDOR_STEDC=1 / JCDF_EIGH_ORMTR=1 select the vendor
+routines already in the process (PyTorch's librocsolver) for those two steps; matrices too large for
+Q to stay in LDS use ormtr.  Falls back to torch.linalg.eigh when an in-kernel hand-off reports a
+timeout.
 """
 from __future__ import annotations
 
@@ -51,6 +53,12 @@ class DeviceEigh:
             self.wb = wb
             self.with_q = n <= int(self.lib.jcdf_sytrd_max_n(1)) and not os.environ.get("JCDF_EIGH_ORMTR")
             self.Q = torch.empty((n, n), **f64) if self.with_q else None
+            self.own_stedc = not os.environ.get("JCDF_EIGH_VENDOR_STEDC")
+            if self.own_stedc:
+                self.dc_wb = int(self.lib.jcdf_stedc_workspace_bytes(n))
+                if self.dc_wb < 0:
+                    raise OSError("jcdf_stedc_workspace_bytes failed")
+                self.dc_work = torch.empty(self.dc_wb // 8 + 8, **f64)
             self.ok = True
         except Exception as e:                                    # vendor library not loadable: plain torch path
             self.reason = repr(e)
@@ -68,7 +76,10 @@ class DeviceEigh:
         p = lambda t: C.c_void_p(t.data_ptr())
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
                                           p(self.Q) if self.with_q else None, p(self.work), self.wb)
-        if rc == 0:
+        if rc == 0 and self.own_stedc:
+            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(self.Cm), n, p(self.dc_work),
+                                            self.dc_wb)
+        elif rc == 0:
             rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
                                           p(self.info))
         if rc == 0 and self.with_q:

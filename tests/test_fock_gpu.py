@@ -298,15 +298,17 @@ def test_water_golden_energy_trail_on_gpu():
     fb.close()
 
 
-@pytest.mark.parametrize("n,ormtr", [(3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0), (1250, 0),
-                                     (64, 1), (130, 1), (510, 1)])
+@pytest.mark.parametrize("n,ormtr", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
+                                     (1250, 0), (64, 1), (130, 1), (510, 1), (64, 2), (510, 2)])
 def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     """Persistent-kernel tridiagonalisation (+ in-kernel Q accumulation and one GEMM, or ormtr) + stedc
     vs numpy (LAPACK) eigh."""
     import torch
     from juliachem_jl_amd.eigh import DeviceEigh
-    if ormtr:
+    if ormtr == 1:
         monkeypatch.setenv("JCDF_EIGH_ORMTR", "1")
+    if ormtr == 2:                                # vendor stedc instead of the library's divide & conquer
+        monkeypatch.setenv("JCDF_EIGH_VENDOR_STEDC", "1")
     rng = np.random.default_rng(n)
     A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
     if n == 64:                                   # degenerate spectrum + zero sub-columns (tau == 0 branches)
@@ -314,7 +316,7 @@ def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     dev = torch.device("cuda", 0)
     eg = DeviceEigh(n, dev)
     assert eg.ok, getattr(eg, "reason", "")
-    assert eg.with_q == (not ormtr)
+    assert eg.with_q == (ormtr != 1) and eg.own_stedc == (ormtr != 2)
     w, U = eg(torch.as_tensor(A, device=dev))
     torch.cuda.synchronize()
     assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")
@@ -481,3 +483,61 @@ def test_rccl_backend_single_rank_collectives(tmp_path):
     B = orc.calculate_B(s.J2c, s.T)
     ref = s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :5])
     assert _rel(np.load(tmp_path / "F.npy"), ref) < 1e-10
+
+
+# ---- device divide & conquer for the tridiagonal stage (csrc/jcdf_dc.hpp) --------------------------------
+def _stedc(d, e):
+    import ctypes as C
+    import torch
+    from juliachem_jl_amd import _lib
+    lib = _lib.load()
+    n = len(d)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    wb = int(lib.jcdf_stedc_workspace_bytes(n))
+    work = torch.empty(wb // 8 + 8, **f64)
+    D = torch.as_tensor(np.asarray(d, dtype=np.float64), **f64).clone()
+    E = torch.as_tensor(np.append(np.asarray(e, dtype=np.float64), 0.0), **f64).clone()
+    Z = torch.full((n, n), float("nan"), **f64)                          # the solver must overwrite everything
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.jcdf_stedc_device(C.c_void_p(st), n, p(D), p(E), p(Z), n, p(work), wb)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(E.cpu().numpy()[:n - 1], np.asarray(e, dtype=np.float64))      # E unchanged
+    return D.cpu().numpy(), Z.cpu().numpy().T
+
+
+def _tridiagonal_cases():
+    rng = np.random.default_rng(42)
+    cases = [("random%d" % n, rng.standard_normal(n), rng.standard_normal(max(n - 1, 0))) for n in (1, 2, 3, 5, 8, 17, 33, 100, 255, 510)]
+    cases.append(("identity", np.ones(64), np.zeros(63)))
+    cases.append(("repeated-diagonal", np.repeat(np.arange(8.0), 8), np.zeros(63)))
+    cases.append(("toeplitz-1-2-1", 2 * np.ones(200), -np.ones(199)))
+    cases.append(("wilkinson21", np.abs(np.arange(-10, 11)).astype(float), np.ones(20)))
+    gl = np.tile(np.abs(np.arange(-10, 11)).astype(float), 10)
+    ge = np.ones(len(gl) - 1); ge[20::21] = 1e-8
+    cases.append(("glued-wilkinson", gl, ge))
+    cases.append(("graded", 10.0 ** -np.arange(0, 60, 0.5), 10.0 ** -np.arange(0.25, 59.5, 0.5)[:119]))
+    cases.append(("clustered", 1.0 + 1e-10 * rng.standard_normal(300), 1e-10 * rng.standard_normal(299)))
+    cases.append(("tiny-couplings", rng.standard_normal(128), 1e-14 * rng.standard_normal(127)))
+    cases.append(("negative-couplings", rng.standard_normal(77), -np.abs(rng.standard_normal(76))))
+    cases.append(("huge-scale", 1e150 * rng.standard_normal(50), 1e150 * rng.standard_normal(49)))
+    cases.append(("tiny-scale", 1e-150 * rng.standard_normal(50), 1e-150 * rng.standard_normal(49)))
+    return cases
+
+
+@pytest.mark.parametrize("name,d,e", _tridiagonal_cases(), ids=[c[0] for c in _tridiagonal_cases()])
+def test_device_stedc_matches_lapack(name, d, e):
+    """jcdf_stedc_device (divide & conquer) against LAPACK on the classical hard tridiagonal matrices:
+    eigenvalues, orthogonality and residual at the level of LAPACK's own dstedc."""
+    import scipy.linalg as sla
+    n = len(d)
+    w, V = _stedc(d, e)
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    wref = sla.eigvalsh_tridiagonal(d, e) if n > 1 else np.array(d)
+    sc = max(np.abs(wref).max(), np.finfo(float).tiny)
+    tol = 1e-13 * max(n, 10)
+    assert np.all(np.isfinite(V)) and np.all(np.diff(w) >= 0)
+    assert np.abs(w - wref).max() / sc < tol
+    assert np.abs(V.T @ V - np.eye(n)).max() < tol
+    assert np.abs(T @ V - V * w[None, :]).max() / sc < tol
