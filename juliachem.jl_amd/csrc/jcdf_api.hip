@@ -1082,17 +1082,31 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         const DcLevel &lv = plan->levels[l];
         const DcMerge *mg = plan->d_merges + lv.merge_off;
         const int maxm = lv.maxm;
-        const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)2 * maxm * 4;
+        const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4;
         if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
         hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
                            wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc);
-        const unsigned gx = (unsigned)std::max(1, (maxm + 31) / 32);          // 32 roots (8 lanes each) per block
-        hipLaunchKernelGGL(k_dc_secular<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org,
-                           wk.mu);
-        hipLaunchKernelGGL(k_dc_zhat<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu,
-                           wk.zhat);
-        hipLaunchKernelGGL(k_dc_vectors<8>, dim3(gx, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat,
-                           wk.col, Za, lda, wk.X, wk.Zp, wk.ldx);
+        // lanes per root / per zhat entry: enough workgroups at the big levels, no idle lanes at the small ones
+        const unsigned nmu = (unsigned)lv.nm;
+        if (maxm >= 256) {
+            const unsigned gx = (unsigned)((maxm + 3) / 4);                   // 4 roots (64 lanes each) per block
+            hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+            hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+        } else if (maxm >= 64) {
+            const unsigned gx = (unsigned)((maxm + 15) / 16);                 // 16 roots (16 lanes each) per block
+            hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+            hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+        } else {
+            const unsigned gx = (unsigned)std::max(1, (maxm + 63) / 64);      // 64 roots (4 lanes each) per block
+            hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+            hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+        }
+        {
+            const int64_t work = (int64_t)roundup(maxm, 16) * (roundup(maxm, 16) + maxm);
+            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, lv.nm) + 1, (work + 1023) / 1024));
+            hipLaunchKernelGGL(k_dc_vectors, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat, wk.col, Za, lda,
+                               wk.X, wk.Zp, wk.ldx);
+        }
         if (maxm >= 96) {
             const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
             hipLaunchKernelGGL(k_dc_update_mfma, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,

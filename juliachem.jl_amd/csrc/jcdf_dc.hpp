@@ -75,7 +75,7 @@ __global__ void k_dc_unscale1(double *__restrict__ w, const double *__restrict__
 // Out (packed at xoff): K (non-deflated count), dl[K] ascending poles, zl[K], col[K] (column of Z, local
 //      index, of pole k), defcol[m-K]/defval[m-K] (deflated eigenpairs), rho.  Givens rotations of the
 //      close-pole deflation are applied to the columns of Z in place.
-// LDS: (2*m + max(m, 256)) doubles + 2*m ints.
+// LDS: (2*m + max(m, 256)) doubles + 3*m ints.
 __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ merges, const double *__restrict__ w,
                                                     const double *__restrict__ e, double *__restrict__ Z, int64_t ldz,
                                                     int *__restrict__ Kout, double *__restrict__ rho_out,
@@ -116,10 +116,62 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
         else        { lo = 0; hi = n1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (dd[mid] <= x) lo = mid + 1; else hi = mid; } perm[(i - n1) + lo] = i; }
     }
     __syncthreads();
-    // deflation scan in ascending order (LAPACK dlaed2), every thread runs the scalar logic on the same
-    // LDS values; the rare rotations are applied to the two columns of Z by the whole workgroup
-    int K = 0, ndef = 0, pj = -1;
+    // Deflation (LAPACK dlaed2).  Common case first, in parallel: poles with negligible z are deflated, and if no
+    // two neighbouring survivors are close enough to be rotated together (that test needs only the ORIGINAL
+    // values as long as no rotation has happened), the survivors are simply compacted in ascending order.
+    int K = 0, ndef = 0;
     const int xo = mg.xoff;
+    int *flag = klist;                                                        // 1 = survivor (by sorted position), then scanned
+    int *scan = reinterpret_cast<int *>(red);                                 // inclusive prefix sums (m ints <= m doubles)
+    for (int t = tid; t < m; t += nthr) flag[t] = (rho * fabs(zz[perm[t]]) <= tol) ? 0 : 1;
+    __syncthreads();
+    for (int t = tid; t < m; t += nthr) scan[t] = flag[t];
+    __syncthreads();
+    for (int off = 1; off < m; off <<= 1) {                                   // Hillis-Steele inclusive scan, m <= 8 * nthr
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t = tid + q * nthr;
+            v[q] = (t < m && t >= off) ? scan[t - off] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t = tid + q * nthr;
+            if (t < m) scan[t] += v[q];
+        }
+        __syncthreads();
+    }
+    // survivors in order: position scan[t]-1; a survivor's predecessor is the survivor with index scan[t]-2
+    int *surv = perm + 2 * m;                                                 // compacted survivors (local column index)
+    for (int t = tid; t < m; t += nthr)
+        if (flag[t]) surv[scan[t] - 1] = perm[t];
+    __syncthreads();
+    K = scan[m - 1];
+    int close = 0;
+    for (int k = 1 + tid; k < K; k += nthr) {
+        const int pj = surv[k - 1], j = surv[k];
+        const double zj = zz[j], zp = zz[pj];
+        // |(d_j - d_pj) c s| <= tol with c s = -z_j z_pj / (z_j^2 + z_pj^2)
+        if (fabs((dd[j] - dd[pj]) * zj * zp) <= tol * (zj * zj + zp * zp)) close = 1;
+    }
+    close = __syncthreads_or(close);
+    if (!close) {
+        ndef = m - K;
+        for (int t = tid; t < m; t += nthr)
+            if (!flag[t]) {
+                const int q = t - scan[t];                                    // deflated so far, in ascending order
+                defcol[xo + q] = perm[t];
+                defval[xo + q] = dd[perm[t]];
+            }
+        __syncthreads();                                                      // flag (== klist) has been read
+        for (int k = tid; k < K; k += nthr) klist[k] = surv[k];
+    } else {
+    // Rare case (close poles: degenerate or clustered spectra): the sequential scan in ascending order, every thread
+    // runs the scalar logic on the same LDS values; the rotations are applied to the two columns of Z by the whole
+    // workgroup.
+    K = 0;
+    int pj = -1;
     for (int t = 0; t < m; ++t) {
         const int j = perm[t];
         const double zj = zz[j];
@@ -130,9 +182,9 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
         }
         if (pj < 0) { pj = j; continue; }
         const double zp = zz[pj], dp = dd[pj], dj = dd[j];
-        const double tau = hypot(zj, zp);
-        const double c = zj / tau, sn = -zp / tau;
-        if (fabs((dj - dp) * c * sn) <= tol) {                               // poles too close: rotate z_pj into z_j
+        if (fabs((dj - dp) * zj * zp) <= tol * (zj * zj + zp * zp)) {         // poles too close: rotate z_pj into z_j
+            const double tau = hypot(zj, zp);
+            const double c = zj / tau, sn = -zp / tau;
             __syncthreads();
             if (tid == 0) {
                 zz[j] = tau;
@@ -161,6 +213,7 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
     if (pj >= 0) {
         if (tid == 0) klist[K] = pj;
         ++K;
+    }
     }
     __syncthreads();
     for (int k = tid; k < K; k += nthr) {
@@ -205,24 +258,25 @@ __device__ void dc_secular_root(int j, int K, const double *__restrict__ d, cons
         dphi = rho * lanes_sum<LANES>(db);
     };
     int o;
-    double lo, hi;                                                            // bracket for mu: f(lo) < 0 < f(hi) (or a pole)
+    double lo, hi, mu;                                                        // bracket for mu: f(lo) < 0 < f(hi) (or a pole)
     double psi, dpsi, phi, dphi;
-    if (j < K - 1) {
-        const double gap = d[j + 1] - d[j];
+    if (j < K - 1) {                                                          // the sign of f at mid-gap picks the nearer pole;
+        const double gap = d[j + 1] - d[j];                                   // the same evaluation is the first iterate
         eval(j, 0.5 * gap, psi, dpsi, phi, dphi);
-        if (1.0 + psi + phi >= 0.0) { o = j; lo = 0.0; hi = 0.5 * gap; }
-        else { o = j + 1; lo = -0.5 * gap; hi = 0.0; }
+        if (1.0 + psi + phi >= 0.0) { o = j; lo = 0.0; hi = 0.5 * gap; mu = hi; }
+        else { o = j + 1; lo = -0.5 * gap; hi = 0.0; mu = lo; }
     } else {
         double zz = 0.0;
         for (int i = lane; i < K; i += LANES) zz += z[i] * z[i];
         zz = lanes_sum<LANES>(zz);
         o = j; lo = 0.0; hi = rho * zz;
         if (!(hi > 0.0)) hi = DC_EPS * fabs(d[j]) + 1e-300;
+        mu = 0.5 * hi;
+        eval(o, mu, psi, dpsi, phi, dphi);
     }
-    double mu = 0.5 * (lo + hi);
     const double dj = d[j] - d[o], dj1 = (j < K - 1) ? d[j + 1] - d[o] : 0.0;
     for (int it = 0; it < 100; ++it) {
-        eval(o, mu, psi, dpsi, phi, dphi);
+        if (it > 0) eval(o, mu, psi, dpsi, phi, dphi);
         const double f = 1.0 + psi + phi;
         const double err = 8.0 * (fabs(phi) + fabs(psi)) + 1.0 + fabs(mu) * (dpsi + dphi);   // dlaed4's erretm
         if (fabs(f) <= DC_EPS * err) break;
@@ -306,10 +360,10 @@ __global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ mer
     }
 }
 
-// ---- vectors: X[i][j] = zhat_i/(d_i - lambda_j) normalised over i (row-major K x K, leading dimension ldx,
-//      rows K .. roundup(K,16)-1 zeroed for the MFMA update), LANES lanes per column j;
-//      and the gather Zp[k][r] = Z[r][col_k] (k-major copy of the non-deflated columns, rows K.. zeroed) -------
-template <int LANES>
+// ---- vectors: X[i][j] = zhat_i/(d_i - lambda_j) (row-major K x K, leading dimension ldx; rows and columns
+//      K .. roundup(K,16)-1 zeroed for the MFMA update; the columns are normalised later, on the rows of the
+//      product, in k_dc_finish) and the gather Zp[k][r] = Z[r][col_k] (k-major copy of the non-deflated
+//      columns, rows K.. zeroed).  Purely elementwise: grid (blocks, merges), grid-stride ----------------------
 __global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                     const double *__restrict__ dl, const int *__restrict__ org,
                                                     const double *__restrict__ mu, const double *__restrict__ zhat,
@@ -319,29 +373,18 @@ __global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ 
     const DcMerge mg = merges[blockIdx.y];
     const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2, s = mg.s;
     const int Kp = (K + 15) / 16 * 16;
-    const double *d = dl + mg.xoff, *zh = zhat + mg.xoff;
-    const int lane = threadIdx.x % LANES, rpb = blockDim.x / LANES;
+    const double *d = dl + mg.xoff, *zh = zhat + mg.xoff, *m_ = mu + mg.xoff;
+    const int *o = org + mg.xoff;
     double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
-    for (int j = blockIdx.x * rpb + threadIdx.x / LANES; j < ((Kp + rpb - 1) / rpb) * rpb; j += gridDim.x * rpb) {
-        double nrm = 0.0;
-        const double dorg = (j < K) ? d[org[mg.xoff + j]] : 0.0, muj = (j < K) ? mu[mg.xoff + j] : 0.0;
-        if (j < K)
-            for (int i = lane; i < K; i += LANES) {
-                const double t = zh[i] / ((d[i] - dorg) - muj);
-                nrm += t * t;
-            }
-#pragma unroll
-        for (int off = LANES / 2; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, LANES);
-        const double inv = (j < K) ? 1.0 / sqrt(nrm) : 0.0;
-        if (j < Kp)
-            for (int i = lane; i < Kp; i += LANES)
-                Xm[(int64_t)i * ldx + j] = (i < K && j < K) ? zh[i] / ((d[i] - dorg) - muj) * inv : 0.0;
-    }
-    // gather (independent of the above): thread-strided over (k, r)
-    const int64_t total = (int64_t)Kp * m;
+    const int64_t nx = (int64_t)Kp * Kp, total = nx + (int64_t)Kp * m;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx / m), r = (int)(idx % m);
-        Zm[(int64_t)k * ldx + r] = (k < K) ? Z[(int64_t)(s + col[mg.xoff + k]) * ldz + s + r] : 0.0;
+        if (idx < nx) {
+            const int i = (int)(idx / Kp), j = (int)(idx % Kp);
+            Xm[(int64_t)i * ldx + j] = (i < K && j < K) ? zh[i] / ((d[i] - d[o[j]]) - m_[j]) : 0.0;
+        } else {
+            const int k = (int)((idx - nx) / m), r = (int)((idx - nx) % m);
+            Zm[(int64_t)k * ldx + r] = (k < K) ? Z[(int64_t)(s + col[mg.xoff + k]) * ldz + s + r] : 0.0;
+        }
     }
 }
 
@@ -434,7 +477,15 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
         for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
         const double *src = (a < K) ? Gm + (int64_t)(xo + a) * ldx : Z + (int64_t)(s + defcol[xo + a - K]) * ldz_in + s;
         double *dst = Znew + (int64_t)(s + rank) * ldz + s;
-        for (int r = lane; r < m; r += 64) dst[r] = src[r];
+        double scale = 1.0;
+        if (a < K) {                                                          // new vector: normalise (X was left unscaled)
+            double nrm = 0.0;
+            for (int r = lane; r < m; r += 64) nrm += src[r] * src[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, 64);
+            scale = 1.0 / sqrt(nrm);
+        }
+        for (int r = lane; r < m; r += 64) dst[r] = src[r] * scale;
         if (lane == 0) wnew[s + rank] = last ? x * sc[0] : x;                 // the last level undoes the scaling
     }
 }
