@@ -38,8 +38,11 @@ __global__ void pingpong(u64 *flag, int a, int b, int rounds, u64 *out, int nele
 
 // all-gather: G participating blocks (those with blockIdx % stride == 0), each publishes `per` granules per round and
 // reads all G*per; rounds back to back.  out[0] = ticks
+// SCOPE: __HIP_MEMORY_SCOPE_AGENT (sc1) or __HIP_MEMORY_SCOPE_WORKGROUP (sc0: coherent in the XCD's L2 only -> valid
+// only when every participant runs on the same XCD)
 // interleave != 0: granule i of a workgroup lives at slot i*G + g (neighbouring slots belong to different
 // workgroups, as when slot == matrix column and columns are dealt out cyclically) instead of g*per + i
+template <int SCOPE>
 __global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 *out, int interleave)
 {
     if (blockIdx.x % stride != 0) return;
@@ -50,9 +53,9 @@ __global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 
     for (int r = 1; r <= rounds; ++r) {
         u64 *b = buf + (size_t)(r & 1) * total;
         for (int i = tid; i < per; i += blockDim.x)
-            __hip_atomic_store(b + (interleave ? i * G + g : g * per + i), (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(b + (interleave ? i * G + g : g * per + i), (u64)r, __ATOMIC_RELAXED, SCOPE);
         for (int i = tid; i < total; i += blockDim.x)
-            SPIN_UNTIL(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u64)r);
+            SPIN_UNTIL(__hip_atomic_load(b + i, __ATOMIC_RELAXED, SCOPE) == (u64)r);
         __syncthreads();
     }
     if (tid == 0 && g == 0) out[0] = wall_clock64() - t0;
@@ -82,12 +85,14 @@ int main()
     for (auto &c : ag) {
         hipMemset(flag, 0, 1 << 20);
         hipMemset(out, 0, 64);
-        hipLaunchKernelGGL(allgather, dim3(c.G * c.stride), dim3(256), 0, 0, flag, c.G, c.stride, c.per, rounds, out, il);
+        hipLaunchKernelGGL(allgather<__HIP_MEMORY_SCOPE_AGENT>, dim3(c.G * c.stride), dim3(256), 0, 0, flag, c.G, c.stride, c.per, rounds, out, il);
         hipDeviceSynchronize();
         u64 h[1];
         hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
         printf("allgather %s G=%2d stride=%d (%s) %3d granules each (%d total): %.3f us per round\n", il ? "interleaved" : "contiguous ", c.G, c.stride,
                c.stride % 8 == 0 ? "one XCD" : "spread", c.per, c.G * c.per, (double)h[0] / 100.0 / rounds);
     }
+    // (workgroup-scope (sc0) granules were tried here for participants on one XCD: the loads are served from the CU's
+    //  L1 and never see the other CU's store - every spin ran into its timeout.  Agent scope is the only usable one.)
     return 0;
 }
