@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Extracts the golden DATA of the reference's own run log
-/root/reference/water_ccpvdz_out.log into tests/golden/water_ccpvdz_rifit.json:
-basis + auxiliary basis exponents/coefficients as printed (:44-157), the
-COM-shifted geometry in bohr (:196-198), SCF settings (:205-216), the printed
-iteration trail (iter, E, dE, Drms; :253-523) and the final energy (:563).
+"""Extracts the golden DATA of the reference's own run logs into tests/golden/*.json:
+  /root/reference/water_ccpvdz_out.log        -> water_ccpvdz_rifit.json   (SURVEY 8c golden #1)
+  /root/reference/test/water_new_algo-4-8.log -> water_631g2dfp_jkfit.json (golden #2: sp shells, f and g functions)
+basis + auxiliary basis exponents/coefficients as printed, the COM-shifted geometry in bohr, SCF
+settings, the printed iteration trail (iter, E, dE, Drms) and the final energy.
 Numbers only — no reference source text is copied.  Run in the build container
 (the reference is not present on the GPU box)."""
 import json
@@ -11,8 +11,11 @@ import os
 import re
 import sys
 
-LOG = "/root/reference/water_ccpvdz_out.log"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "water_ccpvdz_rifit.json")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+CASES = [("/root/reference/water_ccpvdz_out.log", "water_ccpvdz_rifit.json",
+          "water_ccpvdz_out.log (JuliaChem.jl reference run; lines 44-157, 196-198, 205-216, 253-523, 563)"),
+         ("/root/reference/test/water_new_algo-4-8.log", "water_631g2dfp_jkfit.json",
+          "test/water_new_algo-4-8.log (JuliaChem.jl reference run; lines 48-202, 226-228, 244-255, 264-283)")]
 AM = {"S": 0, "P": 1, "D": 2, "F": 3, "G": 4}
 
 
@@ -25,11 +28,13 @@ def parse_basis(lines):
             atoms.append(cur_atom)
             last_id = None
             continue
-        m = re.match(r"\s+(\d+)\s+([SPDFG])\s+(\d+)\s+([-\d.]+)\s+([-\d.]+)\s*$", ln)
+        m = re.match(r"\s+(\d+)\s+([SPDFG]|L \([sp]\))\s+(\d+)\s+([-\d.]+)\s+([-\d.]+)\s*$", ln)
         if m and cur_atom is not None:
-            sid = int(m.group(1))
+            # an "L" (sp) shell is printed as its s part followed by its p part under one shell number: two shells
+            kind = m.group(2)
+            sid = (int(m.group(1)), kind)
             if sid != last_id:
-                cur_shell = {"l": AM[m.group(2)], "exps": [], "coefs": []}
+                cur_shell = {"l": AM[kind[3].upper() if kind.startswith("L") else kind], "exps": [], "coefs": []}
                 cur_atom["shells"].append(cur_shell)
                 last_id = sid
             cur_shell["exps"].append(float(m.group(4)))
@@ -37,7 +42,7 @@ def parse_basis(lines):
     return atoms
 
 
-def main():
+def extract(LOG, OUT, source):
     txt = open(LOG).read().splitlines()
     i_aux = next(i for i, l in enumerate(txt) if "Printing Auxillary basis set" in l)
     i_meta = next(i for i, l in enumerate(txt) if "Printing basis set metadata" in l)
@@ -52,7 +57,7 @@ def main():
             geom.append({"symbol": m.group(1), "center": [float(m.group(k)) for k in (2, 3, 4)]})
     trail = []
     for l in txt:
-        m = re.match(r"^(\d+)\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(\d+\.\d{10})\s*$", l)
+        m = re.match(r"^(\d+)\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})(\s+\d+\.\d{10})?\s*$", l)
         if m:
             trail.append([int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))])
     e_final = float(next(re.search(r"Total SCF Energy: (-?[\d.]+) h", l).group(1) for l in txt if "Total SCF Energy" in l))
@@ -63,7 +68,7 @@ def main():
             m = re.match(r"^%s: (.+)$" % re.escape(key), l.strip())
             if m and key not in meta:
                 meta[key] = m.group(1)
-    out = {"source": "water_ccpvdz_out.log (JuliaChem.jl reference run; lines 44-157, 196-198, 205-216, 253-523, 563)",
+    out = {"source": source,
            "units": "bohr (COM-shifted, as printed)", "atoms": geom,
            "basis": {a["symbol"]: a["shells"] for a in prim}, "aux_basis": {a["symbol"]: a["shells"] for a in aux},
            "atom_order": [a["symbol"] for a in prim], "charges": {"O": 8, "H": 1},
@@ -72,6 +77,11 @@ def main():
     json.dump(out, open(OUT, "w"), indent=1)
     print("wrote", os.path.normpath(OUT), len(trail), "iterations, E =", e_final,
           "| shells", [len(a["shells"]) for a in prim], [len(a["shells"]) for a in aux])
+
+
+def main():
+    for log, name, source in CASES:
+        extract(log, os.path.join(GOLDEN, name), source)
 
 
 if __name__ == "__main__":

@@ -284,6 +284,30 @@ def test_water_golden_energy_trail_on_gpu():
     for (i1, e1, d1, r1), (i2, e2, d2, r2) in zip(scf.trail, g["trail"]):
         assert i1 == i2 and abs(e1 - e2) < 2e-8 and abs(r1 - r2) < 1e-8, (scf.trail[i1 - 1], g["trail"][i1 - 1])
     assert abs(E - g["final_energy"]) < 1e-9
+    fb_keep = fb
+    # golden #2: water / 6-31G(2df,p) / cc-pVTZ-JKFIT (sp shells, f and g functions), 13 printed iterations; the
+    # device path must follow the CPU oracle to 1e-9 on every line (the oracle itself is pinned to the log to
+    # 1e-7, the log's basis being printed with 6 decimals: tests/test_oracle_golden_water.py)
+    w2 = water("631g2dfp")
+    g2 = w2["golden"]
+    fb2 = DeviceFockBuilder(47, 166, w2["n_occ"], w2["aux_shell_nbas"], device=0)
+    fb2.set_metric(w2["J2c"])
+    fb2.set_core_hamiltonian(w2["H"])
+    fb2.exchange_three_center(torch.as_tensor(np.ascontiguousarray(w2["T3"].transpose(2, 1, 0)), device=fb2.device).reshape(-1))
+    scf2 = DeviceSCF(fb2, w2["H"], w2["S"], w2["E_nuc"])
+    for it2 in range(1, 30):
+        E2, dE2, drms2 = scf2.step()
+        if abs(dE2) <= 1e-6 and drms2 <= 1e-6:
+            break
+    assert it2 == len(g2["trail"]) == 13 and abs(E2 - g2["final_energy"]) < 1e-7
+    B2 = orc.calculate_B(w2["J2c"], w2["T3"])
+    from oracle import scf as oscf
+    ref2 = oscf.rhf_df_scf(w2["H"], w2["S"], w2["E_nuc"], 5, lambda C, it: w2["H"] + orc.df_rhf_fock_build_BLAS(B2, C[:, :5]),
+                           dele=1e-6, rmsd=1e-6, niter=20)
+    for (i1, e1, d1, r1), (i2, e2, d2, r2) in zip(scf2.trail, ref2.trail):
+        assert i1 == i2 and abs(e1 - e2) < 1e-9 and abs(r1 - r2) < 1e-8, (i1, e1, e2)
+    fb2.close()
+    fb = fb_keep
     # and through the reference-shaped host operator (df_rhf_fock_build) for one iteration
     bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes(w["prim_shell_nbas"], nels=10),
                                  jc.basis_from_shell_sizes(w["aux_shell_nbas"]))

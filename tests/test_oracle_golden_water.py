@@ -51,3 +51,27 @@ def test_screened_and_sharded_oracle_paths_give_the_same_energy():
                           lambda C, it: orc.df_rhf_fock_build(shards, C, o, w["H"], sd, "screened"),
                           dele=1e-6, rmsd=1e-6, niter=50)
     assert abs(res.energy - w["golden"]["final_energy"]) < 1e-9
+
+
+def test_oracle_reproduces_second_reference_trail_with_f_and_g_functions():
+    """Golden #2: water / 6-31G(2df,p) / cc-pVTZ-JKFIT from the reference's
+    test/water_new_algo-4-8.log — sp shells, Cartesian f functions in the AO basis and f, g functions in the
+    auxiliary basis, 13 printed iterations (this older log also prints the converged one).  The basis is printed
+    with 6 decimals: away from convergence the energy is first-order sensitive to that (<= 1e-5 Eh in iterations
+    1-3, 2e-7 in iteration 4), at convergence second-order: every later line and the final energy agree to 1e-7 Eh."""
+    w = water("631g2dfp")
+    g = w["golden"]
+    o = w["n_occ"]
+    assert w["H"].shape[0] == int(g["settings"]["Number of basis functions"]) == 47
+    assert w["J2c"].shape[0] == int(g["settings"]["Number of auxillary basis functions"]) == 166
+    assert np.allclose(np.diag(w["S"]), 1.0, atol=1e-14)
+    B = orc.calculate_B(w["J2c"], w["T3"])
+    res = oscf.rhf_df_scf(w["H"], w["S"], w["E_nuc"], o,
+                          lambda C, it: w["H"] + orc.df_rhf_fock_build_BLAS(B, C[:, :o]),
+                          dele=1e-6, rmsd=1e-6, niter=20)
+    assert res.converged and res.iterations == len(g["trail"]) == 13
+    for (it, E, dE, drms), (git, gE, gdE, gdrms) in zip(res.trail, g["trail"]):
+        assert it == git
+        assert abs(E - gE) < (1e-5 if it <= 3 else (2e-7 if it == 4 else 1e-7)), (it, E, gE)
+        assert abs(drms - gdrms) < (2e-5 if it <= 3 else 2e-7), (it, drms, gdrms)
+    assert abs(res.energy - g["final_energy"]) < 1e-7, res.energy

@@ -1,6 +1,8 @@
-"""Shared builder of the water / cc-pVDZ / cc-pVDZ-RIFIT case from the golden fixture
-(tests/golden/water_ccpvdz_rifit.json, data extracted from the reference's own log by
-oracle/make_water_golden.py).  Integrals come from the oracle's host integral code."""
+"""Shared builder of the two water cases from the golden fixtures (tests/golden/*.json, data extracted
+from the reference's own logs by oracle/make_water_golden.py):
+  "ccpvdz"  water / cc-pVDZ / cc-pVDZ-RIFIT       (25 AO, 96 aux; d functions)
+  "631g2dfp" water / 6-31G(2df,p) / cc-pVTZ-JKFIT  (47 AO, 166 aux; sp shells, f and g functions)
+Integrals come from the oracle's host integral code."""
 import functools
 import json
 import os
@@ -9,12 +11,13 @@ import numpy as np
 
 from oracle import integrals as gi
 
-FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "water_ccpvdz_rifit.json")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = {"ccpvdz": "water_ccpvdz_rifit.json", "631g2dfp": "water_631g2dfp_jkfit.json"}
 
 
-@functools.lru_cache(maxsize=1)
-def water():
-    d = json.load(open(FIXTURE))
+@functools.lru_cache(maxsize=2)
+def water(case: str = "ccpvdz"):
+    d = json.load(open(os.path.join(GOLDEN, FIXTURES[case])))
     atoms = d["atoms"]
     prim = gi.build_shells(atoms, d["basis"])
     aux = gi.build_shells(atoms, d["aux_basis"])
