@@ -438,6 +438,7 @@ int32_t upload_linv_from_device(jcdf_handle *h, const CholBuffers &w)
 }
 
 // ---- divide & conquer plan (static per n): the merges of every level, bottom-up pairing ------------------
+constexpr int DC_MFMA_MIN = 96;      // merges of a level whose largest merge has at least this many rows use the MFMA update
 struct DcLevel {
     int nm = 0, maxm = 0, has_carry = 0;
     int64_t rows = 0;                // packed rows used by this level
@@ -467,14 +468,15 @@ const DcPlan *dc_plan(int64_t n)
         DcLevel lv;
         lv.merge_off = all.size();
         std::vector<std::pair<int, int>> next;
+        for (size_t b = 0; b + 1 < blocks.size(); b += 2) lv.maxm = std::max(lv.maxm, blocks[b].second + blocks[b + 1].second);
+        const bool pad = lv.maxm >= DC_MFMA_MIN;            // MFMA update: whole 16-row k stages per merge
         int64_t rows = 0;
         for (size_t b = 0; b + 1 < blocks.size(); b += 2) {
             DcMerge mg{blocks[b].first, blocks[b].second, blocks[b + 1].second, (int)rows};
             const int m = mg.n1 + mg.n2;
-            rows += roundup(m, 16);
+            rows += pad ? roundup(m, 16) : m;
             all.push_back(mg);
             lv.nm++;
-            lv.maxm = std::max(lv.maxm, m);
             next.push_back({mg.s, m});
         }
         if (blocks.size() % 2) {                                // odd block out: carried to the next level unchanged;
@@ -1084,41 +1086,48 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         const int maxm = lv.maxm;
         const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4;
         if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
-        hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
-                           wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc);
-        // lanes per root / per zhat entry: enough workgroups at the big levels, no idle lanes at the small ones
-        const unsigned nmu = (unsigned)lv.nm;
-        if (maxm >= 256) {
-            const unsigned gx = (unsigned)((maxm + 3) / 4);                   // 4 roots (64 lanes each) per block
-            hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-            hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
-        } else if (maxm >= 64) {
-            const unsigned gx = (unsigned)((maxm + 15) / 16);                 // 16 roots (16 lanes each) per block
-            hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-            hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+        static const int fuse_max = getenv("JCDF_DC_FUSE_MAX") ? atoi(getenv("JCDF_DC_FUSE_MAX")) : 32;
+        if (maxm <= fuse_max) {       // tiny merges: one launch per level instead of six
+            hipLaunchKernelGGL(k_dc_merge_small<4>, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
+                               wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc, wk.org, wk.mu, wk.zhat, wk.X, wk.Zp, wk.ldx, wk.G, Zn,
+                               ldn, wn, l == L - 1 ? 1 : 0);
         } else {
-            const unsigned gx = (unsigned)std::max(1, (maxm + 63) / 64);      // 64 roots (4 lanes each) per block
-            hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-            hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+            hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
+                               wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc);
+            // lanes per root / per zhat entry: enough workgroups at the big levels, no idle lanes at the small ones
+            const unsigned nmu = (unsigned)lv.nm;
+            if (maxm >= 256) {
+                const unsigned gx = (unsigned)((maxm + 3) / 4);                   // 4 roots (64 lanes each) per block
+                hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+            } else if (maxm >= 64) {
+                const unsigned gx = (unsigned)((maxm + 15) / 16);                 // 16 roots (16 lanes each) per block
+                hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+            } else {
+                const unsigned gx = (unsigned)std::max(1, (maxm + 63) / 64);      // 64 roots (4 lanes each) per block
+                hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+            }
+            {
+                const int64_t work = (int64_t)roundup(maxm, 16) * (roundup(maxm, 16) + maxm);
+                const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, lv.nm) + 1, (work + 1023) / 1024));
+                hipLaunchKernelGGL(k_dc_vectors, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat, wk.col, Za, lda,
+                                   wk.X, wk.Zp, wk.ldx, maxm >= DC_MFMA_MIN ? 1 : 0);
+            }
+            if (maxm >= DC_MFMA_MIN) {
+                const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
+                hipLaunchKernelGGL(k_dc_update_mfma, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
+                                   wk.X, wk.Zp, wk.ldx, wk.G);
+            } else {
+                const unsigned tiles = (unsigned)std::min(64, ((maxm + 15) / 16) * ((maxm + 15) / 16));
+                hipLaunchKernelGGL(k_dc_update_simple, dim3(tiles, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.X, wk.Zp, wk.ldx,
+                                   wk.G);
+            }
+            const unsigned fx = (unsigned)std::max(1, (maxm + 7) / 8);
+            hipLaunchKernelGGL(k_dc_finish, dim3(fx, (unsigned)lv.nm), dim3(256), (size_t)maxm * 8, st, mg, wk.K, wk.dl, wk.org, wk.mu,
+                               wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn, wk.sc, l == L - 1 ? 1 : 0);
         }
-        {
-            const int64_t work = (int64_t)roundup(maxm, 16) * (roundup(maxm, 16) + maxm);
-            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, lv.nm) + 1, (work + 1023) / 1024));
-            hipLaunchKernelGGL(k_dc_vectors, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat, wk.col, Za, lda,
-                               wk.X, wk.Zp, wk.ldx);
-        }
-        if (maxm >= 96) {
-            const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
-            hipLaunchKernelGGL(k_dc_update_mfma, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
-                               wk.X, wk.Zp, wk.ldx, wk.G);
-        } else {
-            const unsigned tiles = (unsigned)std::min(64, ((maxm + 15) / 16) * ((maxm + 15) / 16));
-            hipLaunchKernelGGL(k_dc_update_simple, dim3(tiles, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.X, wk.Zp, wk.ldx,
-                               wk.G);
-        }
-        const unsigned fx = (unsigned)std::max(1, (maxm + 7) / 8);
-        hipLaunchKernelGGL(k_dc_finish, dim3(fx, (unsigned)lv.nm), dim3(256), (size_t)maxm * 8, st, mg, wk.K, wk.dl, wk.org, wk.mu,
-                           wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn, wk.sc, l == L - 1 ? 1 : 0);
         if (lv.has_carry)
             hipLaunchKernelGGL(k_dc_carry, dim3(16, 1), dim3(256), 0, st, mg + lv.nm, Za, lda, Zn, ldn, wa, wn);
         std::swap(Za, Zn);

@@ -28,6 +28,18 @@ struct DcMerge {          // one merge of the tree: rows/columns [s, s + n1 + n2
 
 constexpr double DC_EPS = 1.1102230246251565e-16;      // unit roundoff (LAPACK dlamch('E'))
 
+// Wave-uniform reads of words that an earlier PHASE OF THE SAME KERNEL may have written (k_dc_merge_small runs all
+// phases of a merge in one workgroup): forced onto the vector path — a scalar load could be served from a scalar-
+// cache line that another workgroup pulled in before the word was written.
+__device__ __forceinline__ int dc_ld(const int *p)
+{
+    return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double dc_ld(const double *p)
+{
+    return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- scaling (LAPACK dstedc scales to unit max-norm: the tolerances and products below assume O(1) data) --
 // sc[0] = max(|d|, |e|) (1 for the zero matrix), sc[1] = 1/sc[0].  One workgroup.
 __global__ __launch_bounds__(256) void k_dc_norm(const double *__restrict__ d, const double *__restrict__ e, int n,
@@ -76,15 +88,15 @@ __global__ void k_dc_unscale1(double *__restrict__ w, const double *__restrict__
 //      index, of pole k), defcol[m-K]/defval[m-K] (deflated eigenpairs), rho.  Givens rotations of the
 //      close-pole deflation are applied to the columns of Z in place.
 // LDS: (2*m + max(m, 256)) doubles + 3*m ints.
-__global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ merges, const double *__restrict__ w,
+__device__ __forceinline__ void dc_prepare_body(const DcMerge *__restrict__ merges, const double *__restrict__ w,
                                                     const double *__restrict__ e, double *__restrict__ Z, int64_t ldz,
                                                     int *__restrict__ Kout, double *__restrict__ rho_out,
                                                     double *__restrict__ dl, double *__restrict__ zl, int *__restrict__ col,
                                                     int *__restrict__ defcol, double *__restrict__ defval,
-                                                    const double *__restrict__ sc)
+                                                    const double *__restrict__ sc, int mi, int vbx, int vgx, double *dyn_smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const DcMerge mg = merges[blockIdx.x];
+    double *sm = dyn_smem;
+    const DcMerge mg = merges[mi];
     const int s = mg.s, n1 = mg.n1, m = mg.n1 + mg.n2, tid = threadIdx.x, nthr = blockDim.x;
     double *dd = sm, *zz = sm + m, *red = sm + 2 * m;                        // by local column index
     int *perm = reinterpret_cast<int *>(sm + 2 * m + (m > 256 ? m : 256));   // sorted position -> local index
@@ -223,9 +235,20 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
         col[xo + k] = c;
     }
     if (tid == 0) {
-        Kout[blockIdx.x] = K;
-        rho_out[blockIdx.x] = rho;
+        Kout[mi] = K;
+        rho_out[mi] = rho;
     }
+}
+
+__global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ merges, const double *__restrict__ w,
+                                                    const double *__restrict__ e, double *__restrict__ Z, int64_t ldz,
+                                                    int *__restrict__ Kout, double *__restrict__ rho_out,
+                                                    double *__restrict__ dl, double *__restrict__ zl, int *__restrict__ col,
+                                                    int *__restrict__ defcol, double *__restrict__ defval,
+                                                    const double *__restrict__ sc)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_prepare_body(merges, w, e, Z, ldz, Kout, rho_out, dl, zl, col, defcol, defval, sc, (int)blockIdx.x, 0, 1, dyn_smem);
 }
 
 // ---- secular equation ------------------------------------------------------------------------------------
@@ -316,36 +339,46 @@ __device__ void dc_secular_root(int j, int K, const double *__restrict__ d, cons
 
 // grid: (blocks, merges); LANES lanes per root
 template <int LANES>
+__device__ __forceinline__ void dc_secular_body(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                    const double *__restrict__ rho_in, const double *__restrict__ dl,
+                                                    const double *__restrict__ zl, int *__restrict__ org,
+                                                    double *__restrict__ mu, int mi, int vbx, int vgx, double *dyn_smem)
+{
+    const DcMerge mg = merges[mi];
+    const int K = dc_ld(Kin + mi);
+    const int lane = threadIdx.x % LANES;
+    const int rpb = blockDim.x / LANES;                                       // roots per block
+    for (int j = vbx * rpb + threadIdx.x / LANES; j < ((K + rpb - 1) / rpb) * rpb; j += vgx * rpb) {
+        // (whole groups stay in the loop together: __shfl needs every lane of the group)
+        if (j < K) dc_secular_root<LANES>(j, K, dl + mg.xoff, zl + mg.xoff, dc_ld(rho_in + mi), lane, org + mg.xoff + j, mu + mg.xoff + j);
+    }
+}
+
+template <int LANES>
 __global__ __launch_bounds__(256) void k_dc_secular(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                     const double *__restrict__ rho_in, const double *__restrict__ dl,
                                                     const double *__restrict__ zl, int *__restrict__ org,
                                                     double *__restrict__ mu)
 {
-    const DcMerge mg = merges[blockIdx.y];
-    const int K = Kin[blockIdx.y];
-    const int lane = threadIdx.x % LANES;
-    const int rpb = blockDim.x / LANES;                                       // roots per block
-    for (int j = blockIdx.x * rpb + threadIdx.x / LANES; j < ((K + rpb - 1) / rpb) * rpb; j += gridDim.x * rpb) {
-        // (whole groups stay in the loop together: __shfl needs every lane of the group)
-        if (j < K) dc_secular_root<LANES>(j, K, dl + mg.xoff, zl + mg.xoff, rho_in[blockIdx.y], lane, org + mg.xoff + j, mu + mg.xoff + j);
-    }
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_secular_body<LANES>(merges, Kin, rho_in, dl, zl, org, mu, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
 
 // ---- zhat (Loewner / Gu-Eisenstat): the z for which the computed roots are the exact eigenvalues ----------
 // zhat_i = sign(z_i) sqrt( (lambda_i - d_i) prod_{j != i} (lambda_j - d_i)/(d_j - d_i) ),
 // with d_i - lambda_j = (d_i - d_{o_j}) - mu_j.  LANES lanes per i.
 template <int LANES>
-__global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+__device__ __forceinline__ void dc_zhat_body(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                  const double *__restrict__ dl, const double *__restrict__ zl,
                                                  const int *__restrict__ org, const double *__restrict__ mu,
-                                                 double *__restrict__ zhat)
+                                                 double *__restrict__ zhat, int mi, int vbx, int vgx, double *dyn_smem)
 {
-    const DcMerge mg = merges[blockIdx.y];
-    const int K = Kin[blockIdx.y];
+    const DcMerge mg = merges[mi];
+    const int K = dc_ld(Kin + mi);
     const double *d = dl + mg.xoff, *m_ = mu + mg.xoff;
     const int *o = org + mg.xoff;
     const int lane = threadIdx.x % LANES, rpb = blockDim.x / LANES;
-    for (int i = blockIdx.x * rpb + threadIdx.x / LANES; i < ((K + rpb - 1) / rpb) * rpb; i += gridDim.x * rpb) {
+    for (int i = vbx * rpb + threadIdx.x / LANES; i < ((K + rpb - 1) / rpb) * rpb; i += vgx * rpb) {
         double p = 1.0;
         if (i < K) {
             const double di = d[i];
@@ -360,24 +393,34 @@ __global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ mer
     }
 }
 
+template <int LANES>
+__global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                 const double *__restrict__ dl, const double *__restrict__ zl,
+                                                 const int *__restrict__ org, const double *__restrict__ mu,
+                                                 double *__restrict__ zhat)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_zhat_body<LANES>(merges, Kin, dl, zl, org, mu, zhat, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
+}
+
 // ---- vectors: X[i][j] = zhat_i/(d_i - lambda_j) (row-major K x K, leading dimension ldx; rows and columns
-//      K .. roundup(K,16)-1 zeroed for the MFMA update; the columns are normalised later, on the rows of the
+//      K .. roundup(K,16)-1 zeroed when the MFMA update follows (pad16); the columns are normalised later, on the rows of the
 //      product, in k_dc_finish) and the gather Zp[k][r] = Z[r][col_k] (k-major copy of the non-deflated
 //      columns, rows K.. zeroed).  Purely elementwise: grid (blocks, merges), grid-stride ----------------------
-__global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+__device__ __forceinline__ void dc_vectors_body(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                     const double *__restrict__ dl, const int *__restrict__ org,
                                                     const double *__restrict__ mu, const double *__restrict__ zhat,
                                                     const int *__restrict__ col, const double *__restrict__ Z, int64_t ldz,
-                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx)
+                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx, int pad16, int mi, int vbx, int vgx, double *dyn_smem)
 {
-    const DcMerge mg = merges[blockIdx.y];
-    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2, s = mg.s;
-    const int Kp = (K + 15) / 16 * 16;
+    const DcMerge mg = merges[mi];
+    const int K = dc_ld(Kin + mi), m = mg.n1 + mg.n2, s = mg.s;
+    const int Kp = pad16 ? (K + 15) / 16 * 16 : K;       // the MFMA update wants whole 16-row k stages
     const double *d = dl + mg.xoff, *zh = zhat + mg.xoff, *m_ = mu + mg.xoff;
     const int *o = org + mg.xoff;
     double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
     const int64_t nx = (int64_t)Kp * Kp, total = nx + (int64_t)Kp * m;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)vbx * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)vgx * blockDim.x) {
         if (idx < nx) {
             const int i = (int)(idx / Kp), j = (int)(idx % Kp);
             Xm[(int64_t)i * ldx + j] = (i < K && j < K) ? zh[i] / ((d[i] - d[o[j]]) - m_[j]) : 0.0;
@@ -388,20 +431,30 @@ __global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                    const double *__restrict__ dl, const int *__restrict__ org,
+                                                    const double *__restrict__ mu, const double *__restrict__ zhat,
+                                                    const int *__restrict__ col, const double *__restrict__ Z, int64_t ldz,
+                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx, int pad16)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_vectors_body(merges, Kin, dl, org, mu, zhat, col, Z, ldz, X, Zp, ldx, pad16, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
+}
+
 // ---- update: G[j][r] = sum_k X[k][j] * Zp[k][r]  (k-major operands; G row j = new eigenvector j over rows r) -
 // small/unaligned version: one thread per (j, r), 16 x 16 tiles through LDS.  grid: (tiles, merges)
-__global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+__device__ __forceinline__ void dc_update_simple_body(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                           const double *__restrict__ X, const double *__restrict__ Zp,
-                                                          int64_t ldx, double *__restrict__ Gm)
+                                                          int64_t ldx, double *__restrict__ Gm, int mi, int vbx, int vgx, double *dyn_smem)
 {
     __shared__ double xs[16][17], zs[16][17];
-    const DcMerge mg = merges[blockIdx.y];
-    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2;
+    const DcMerge mg = merges[mi];
+    const int K = dc_ld(Kin + mi), m = mg.n1 + mg.n2;
     const int tj = (K + 15) / 16, tr = (m + 15) / 16;
     const double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
     double *G = Gm + (int64_t)mg.xoff * ldx;
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-    for (int tile = blockIdx.x; tile < tj * tr; tile += gridDim.x) {
+    for (int tile = vbx; tile < tj * tr; tile += vgx) {
         const int j0 = (tile / tr) * 16, r0 = (tile % tr) * 16;
         double acc = 0.0;
         for (int k0 = 0; k0 < K; k0 += 16) {
@@ -414,6 +467,14 @@ __global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restr
         }
         if (j0 + ty < K && r0 + tx < m) G[(int64_t)(j0 + ty) * ldx + r0 + tx] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                          const double *__restrict__ X, const double *__restrict__ Zp,
+                                                          int64_t ldx, double *__restrict__ Gm)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_update_simple_body(merges, Kin, X, Zp, ldx, Gm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
 
 // MFMA version for the large merges: 64 x 64 output tile per workgroup.  grid: (tiles, merges)
@@ -452,22 +513,22 @@ __global__ __launch_bounds__(256) void k_dc_update_mfma(const DcMerge *__restric
 
 // ---- finish: the m eigenpairs of the merged block (K new ones from G, m-K deflated ones from Z) sorted
 //      ascending into Znew / wnew.  grid: (blocks, merges); each block ranks and copies a slice of the pairs --
-__global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+__device__ __forceinline__ void dc_finish_body(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                    const double *__restrict__ dl, const int *__restrict__ org,
                                                    const double *__restrict__ mu, const int *__restrict__ defcol,
                                                    const double *__restrict__ defval, const double *__restrict__ Gm,
                                                    int64_t ldx, const double *__restrict__ Z, int64_t ldz_in,
                                                    double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew,
-                                                   const double *__restrict__ sc, int last)
+                                                   const double *__restrict__ sc, int last, int mi, int vbx, int vgx, double *dyn_smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double vals[];            // m values: new roots then deflated
-    const DcMerge mg = merges[blockIdx.y];
-    const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2, s = mg.s, xo = mg.xoff;
+    double *vals = dyn_smem;                                                  // m values: new roots then deflated
+    const DcMerge mg = merges[mi];
+    const int K = dc_ld(Kin + mi), m = mg.n1 + mg.n2, s = mg.s, xo = mg.xoff;
     for (int a = threadIdx.x; a < m; a += blockDim.x)
         vals[a] = (a < K) ? dl[xo + org[xo + a]] + mu[xo + a] : defval[xo + a - K];
     __syncthreads();
-    const int per = (m + gridDim.x - 1) / gridDim.x;
-    const int a0 = blockIdx.x * per, a1 = min(m, a0 + per);
+    const int per = (m + vgx - 1) / vgx;
+    const int a0 = vbx * per, a1 = min(m, a0 + per);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int a = a0 + wave; a < a1; a += nw) {                                // one wave per eigenpair
         const double x = vals[a];
@@ -475,7 +536,7 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
         for (int b = lane; b < m; b += 64) rank += (vals[b] < x || (vals[b] == x && b < a)) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
-        const double *src = (a < K) ? Gm + (int64_t)(xo + a) * ldx : Z + (int64_t)(s + defcol[xo + a - K]) * ldz_in + s;
+        const double *src = (a < K) ? Gm + (int64_t)(xo + a) * ldx : Z + (int64_t)(s + dc_ld(defcol + xo + a - K)) * ldz_in + s;
         double *dst = Znew + (int64_t)(s + rank) * ldz + s;
         double scale = 1.0;
         if (a < K) {                                                          // new vector: normalise (X was left unscaled)
@@ -488,6 +549,43 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
         for (int r = lane; r < m; r += 64) dst[r] = src[r] * scale;
         if (lane == 0) wnew[s + rank] = last ? x * sc[0] : x;                 // the last level undoes the scaling
     }
+}
+
+__global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
+                                                   const double *__restrict__ dl, const int *__restrict__ org,
+                                                   const double *__restrict__ mu, const int *__restrict__ defcol,
+                                                   const double *__restrict__ defval, const double *__restrict__ Gm,
+                                                   int64_t ldx, const double *__restrict__ Z, int64_t ldz_in,
+                                                   double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew,
+                                                   const double *__restrict__ sc, int last)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    dc_finish_body(merges, Kin, dl, org, mu, defcol, defval, Gm, ldx, Z, ldz_in, Znew, ldz, wnew, sc, last, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
+}
+
+// ---- small merges (m <= 64): all phases of one merge by ONE workgroup in ONE launch (six launches per level
+//      are pure latency at these sizes).  Pointers deliberately without const/__restrict__: phases read what
+//      earlier phases wrote ---------------------------------------------------------------------------------
+template <int LANES>
+__global__ __launch_bounds__(256) void k_dc_merge_small(const DcMerge *merges, double *w, const double *e, double *Z, int64_t ldz,
+                                                        int *Kbuf, double *rho, double *dl, double *zl, int *col, int *defcol,
+                                                        double *defval, const double *sc, int *org, double *mu, double *zhat,
+                                                        double *X, double *Zp, int64_t ldx, double *G, double *Znew, int64_t ldzn,
+                                                        double *wnew, int last)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+    const int mi = blockIdx.x;
+    dc_prepare_body(merges, w, e, Z, ldz, Kbuf, rho, dl, zl, col, defcol, defval, sc, mi, 0, 1, dyn_smem);
+    __syncthreads();
+    dc_secular_body<LANES>(merges, Kbuf, rho, dl, zl, org, mu, mi, 0, 1, dyn_smem);
+    __syncthreads();
+    dc_zhat_body<LANES>(merges, Kbuf, dl, zl, org, mu, zhat, mi, 0, 1, dyn_smem);
+    __syncthreads();
+    dc_vectors_body(merges, Kbuf, dl, org, mu, zhat, col, Z, ldz, X, Zp, ldx, 0, mi, 0, 1, dyn_smem);
+    __syncthreads();
+    dc_update_simple_body(merges, Kbuf, X, Zp, ldx, G, mi, 0, 1, dyn_smem);
+    __syncthreads();
+    dc_finish_body(merges, Kbuf, dl, org, mu, defcol, defval, G, ldx, Z, ldz, Znew, ldzn, wnew, sc, last, mi, 0, 1, dyn_smem);
 }
 
 // rows/columns of blocks that are not merged at this level (odd leaf carried up) are copied unchanged
