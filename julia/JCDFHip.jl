@@ -84,9 +84,9 @@ function setup!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
             pq_p[idx] = pp - 1; pq_q[idx] = qq - 1
         end
     end
-    # L^-1 on the host, GPUDF.jl:890-891
-    LinearAlgebra.LAPACK.potrf!('L', two_center_integrals)
-    LinearAlgebra.LAPACK.trtri!('L', 'N', two_center_integrals)
+    # L = chol((P|Q)) and L^-1 are formed on each device by jcdf_set_metric (the placement of
+    # CUSOLVER.potrf!/trtri! in DenseGPUDF.jl:185-193; the screened path does them with host LAPACK at
+    # GPUDF.jl:890-891 — with L^-1 already in hand call jcdf_set_metric_inverse instead)
 
     device_Q_indices, _, device_Q_range_lengths, _ =
         calculate_device_ranges_GPU(scf_data, num_devices, n_ranks, basis_sets)                             # GPUDF.jl:1026-1056
@@ -102,7 +102,7 @@ function setup!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
         check(h, ccall((:jcdf_configure, libjcdf), Int32,
                        (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
                        h, N, A, first(rows) - 1, last(rows), occ, P, pq_p, pq_q))
-        check(h, ccall((:jcdf_set_metric_inverse, libjcdf), Int32, (Ptr{Cvoid}, Ptr{Float64}), h, two_center_integrals))
+        check(h, ccall((:jcdf_set_metric, libjcdf), Int32, (Ptr{Cvoid}, Ptr{Float64}), h, two_center_integrals))
         check(h, ccall((:jcdf_set_core_hamiltonian, libjcdf), Int32, (Ptr{Cvoid}, Ptr{Float64}),
                        h, (rank == 0 && dev == 1) ? H : C_NULL))                                            # GPUDF.jl:158-161
         push!(gd.handles, h)
