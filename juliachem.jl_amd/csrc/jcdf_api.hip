@@ -1025,7 +1025,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     hipStream_t st = (hipStream_t)stream;
     char *w = (char *)d_work;
     int *err = (int *)(w + 8);
-    jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 2 * (n + 1), *hg = yg + 2 * n;
+    jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 2 * (n + 2), *hg = yg + 2 * ((n + 1) & ~(int64_t)1);
     // tags restart at 1 every call: all granules (and the error word) are zeroed first
     if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
     (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

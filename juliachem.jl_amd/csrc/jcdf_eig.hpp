@@ -71,50 +71,79 @@ __device__ __forceinline__ bool spin_ok(unsigned &spins, u64 &t0, int *err)
     return true;
 }
 
-// Returns false on timeout / peer failure (error word set).
-__device__ __forceinline__ bool sub(const u64 *g, int idx, unsigned tag, double *out, int *err)
-{
-    u64 a;
-    unsigned spins = 0;
-    u64 t0 = 0;
-    for (;;) {
-        a = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(a & 3ULL) == tag) break;
-        if (!spin_ok(spins, t0, err)) return false;
-    }
-    *out = __longlong_as_double((long long)(a & ~3ULL));
-    return true;
-}
-
-// Batched form: elements idx = first + e*stride (e < 8, idx < count) are requested together, so a
-// thread pays one memory round trip for all of them instead of one per element.
-// `beat` (optional): one more word polled in the same round trips, only its tag (`btag`) matters.
-__device__ __forceinline__ bool sub8(const u64 *g, int first, int stride, int count, unsigned tag, double *dst, int *err,
-                                     const u64 *beat = nullptr, unsigned btag = 0)
+// granule pairs (first + e*stride, +1), e < NP, below `count`; `beat` (optional): one more word, only its tag matters.
+// (16-byte polls — two granules per request — were measured too: no gain inside this kernel, tools/xcd_pingpong.hip
+// has the stand-alone numbers; every poll here is an 8-byte agent-scope atomic load.)
+// SYTRD_POLL_DEPTH attempts can be kept in flight, SYTRD_POLL_GAP s_sleep units apart (a poll is a ~1.4 us round
+// trip, so a word that lands just after an attempt was issued is seen a whole round trip later) — measured: every
+// extra attempt in flight makes the kernel SLOWER (depth 2: +7 %, depth 4: +15 %), and so does any delay before the
+// first attempt; polls on a line that is about to be written compete with that write.  Depth 1, no delay.
+#ifndef SYTRD_POLL_DEPTH
+#define SYTRD_POLL_DEPTH 1
+#endif
+#ifndef SYTRD_POLL_GAP
+#define SYTRD_POLL_GAP 4
+#endif
+template <int NP>
+__device__ __forceinline__ bool sub_pairs(const u64 *g, int first, int stride, int count, unsigned tag, double *dst, int *err,
+                                          const u64 *beat, unsigned btag)
 {
     unsigned pending = beat ? 1u << 8 : 0u;
+    const u64 *p[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-        if (first + e * stride < count) pending |= 1u << e;
+    for (int e = 0; e < 4; ++e) {
+        const bool in = e < NP && first + e * stride < count;
+        p[e] = g + (in ? first + e * stride : 0);                             // slots beyond the end re-read pair 0 (unused)
+        if (in) pending |= 1u << (2 * e);
+        if (in && first + e * stride + 1 < count) pending |= 2u << (2 * e);
+    }
     unsigned spins = 0;
     u64 t0 = 0;
     while (pending) {
-        u64 a[8], b = 0;
+        u64 lo[SYTRD_POLL_DEPTH][NP], hi[SYTRD_POLL_DEPTH][NP], b[SYTRD_POLL_DEPTH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (pending & (1u << e)) a[e] = __hip_atomic_load(g + first + e * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pending & (1u << 8)) b = __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = 0; a < SYTRD_POLL_DEPTH; ++a) {
+            if (a > 0) __builtin_amdgcn_s_sleep(SYTRD_POLL_GAP);
+            b[a] = (pending & (1u << 8)) ? __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if ((pending & (1u << e)) && (unsigned)(a[e] & 3ULL) == tag) {
-                dst[first + e * stride] = __longlong_as_double((long long)(a[e] & ~3ULL));
-                pending &= ~(1u << e);
+            for (int e = 0; e < NP; ++e) {
+                lo[a][e] = (pending & (1u << (2 * e))) ? __hip_atomic_load(p[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                hi[a][e] = (pending & (2u << (2 * e))) ? __hip_atomic_load(p[e] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
-        if ((pending & (1u << 8)) && (unsigned)(b & 3ULL) == btag) pending &= ~(1u << 8);
+        }
+#pragma unroll
+        for (int a = 0; a < SYTRD_POLL_DEPTH; ++a) {                          // oldest attempt first (loads return in order)
+#pragma unroll
+            for (int e = 0; e < NP; ++e) {
+                if ((pending & (1u << (2 * e))) && (unsigned)(lo[a][e] & 3ULL) == tag) {
+                    dst[first + e * stride] = __longlong_as_double((long long)(lo[a][e] & ~3ULL));
+                    pending &= ~(1u << (2 * e));
+                }
+                if ((pending & (2u << (2 * e))) && (unsigned)(hi[a][e] & 3ULL) == tag) {
+                    dst[first + e * stride + 1] = __longlong_as_double((long long)(hi[a][e] & ~3ULL));
+                    pending &= ~(2u << (2 * e));
+                }
+            }
+            if ((pending & (1u << 8)) && (unsigned)(b[a] & 3ULL) == btag) pending &= ~(1u << 8);
+            if (!pending) break;
+        }
         if (!pending) break;
         if (!spin_ok(spins, t0, err)) return false;
     }
     return true;
+}
+
+// all `count` granules of a buffer (+ optional heartbeat word) by the whole workgroup, adjacent pairs per lane
+__device__ __forceinline__ bool sub_all(const u64 *g, int count, unsigned tag, double *dst, int *err, const u64 *beat = nullptr,
+                                        unsigned btag = 0)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    bool ok = true;
+    if (count <= 2 * nthr) return sub_pairs<1>(g, 2 * tid, 2 * nthr, count, tag, dst, err, beat, btag);
+    if (count <= 4 * nthr) return sub_pairs<2>(g, 2 * tid, 2 * nthr, count, tag, dst, err, beat, btag);
+    for (int i0 = 2 * tid, first = 1; (i0 < count || first) && ok; i0 += 8 * nthr, first = 0)
+        ok = sub_pairs<4>(g, i0, 2 * nthr, count, tag, dst, err, first ? beat : nullptr, btag);
+    return ok;
 }
 
 // ---- reductions on the VALU (DPP), not through the LDS crossbar ------------------------------
@@ -200,7 +229,7 @@ __device__ __forceinline__ bool block_all(bool ok, double *red, unsigned &rs)
 constexpr int SYTRD_CB = 8;      // local columns processed together (independent accumulators)
 
 // A: n x n symmetric (full storage, lda >= n).  Workspace: `err` word + granule buffers
-//   vg: 2 x (n+1) granules (slot n of a half carries tau), yg: 2 x n, hg: 2 x gridDim.x (heartbeats),
+//   vg: 2 x (n+2) granules (v_k in slots 0..m-1, tau_k in slot m), yg: 2 x roundup(n,2), hg: 2 x gridDim.x (heartbeats),
 // all zeroed before launch.
 // LDS: ((Qout ? 2 : 1) * ncol_max * n + 2 n + 32) doubles, ncol_max = ceil(n / gridDim.x).
 // Qout (optional, n x n row-major): the orthogonal matrix Q = H_0 H_1 ... H_{n-3} of A = Q T Q^T,
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
     auto reflector = [&](int k, double xnorm2) {
         const int m = n - k - 1, buf = k & 1;
         const unsigned tag = step_tag(k);
-        u64 *vb = vg + (size_t)buf * (n + 1);
+        u64 *vb = vg + (size_t)buf * (n + 2);                               // (n + 2: even, 16-byte aligned halves)
         double *x = slab + (size_t)(k / G) * n + (k + 1);
         const double alpha = x[0];
         double tau = 0.0, beta = alpha, scale = 0.0;
@@ -256,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             scale = 1.0 / (alpha - beta);
         }
         __syncthreads();                                  // everyone has read x[0]
-        if (tid == 0) pub(vb, n, tau, tag);
+        if (tid == 0) pub(vb, m, tau, tag);                                // slot m, right behind the m entries of v
         for (int i = tid; i < m; i += nthr) {
             const double v = (i == 0) ? 1.0 : tag_trunc(x[i] * scale);
             pub(vb, i, v, tag);
@@ -282,16 +311,15 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
         const int m = n - k - 1;                          // rows k+1 .. n-1
         const int buf = k & 1;
         const unsigned tag = step_tag(k);
-        const u64 *vb = vg + (size_t)buf * (n + 1);
-        u64 *yb = yg + (size_t)buf * n;
+        const u64 *vb = vg + (size_t)buf * (n + 2);
+        u64 *yb = yg + (size_t)buf * ((n + 1) & ~1);                        // even stride: 16-byte aligned halves
 
         // ---- everyone: v, tau -> LDS (each thread waits for its own elements)
         bool ok = true;
-        for (int i0 = tid; i0 < m && ok; i0 += 8 * nthr) ok = sub8(vb, i0, nthr, m, tag, vs, err);
-        if (tid == 0 && ok) ok = sub(vb, n, tag, vs + (n - 1), err);
+        ok = sub_all(vb, m + 1, tag, vs, err);                                // v and tau (slot m)
         if (!block_all(ok, red, rs)) return;
         SYTRD_TICK(0);                                    // waited for v
-        const double tau = vs[n - 1];
+        const double tau = vs[m];
         const int c0 = (k + 1 - g + G - 1) / G;           // first local column with j > k
         const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
 
@@ -346,13 +374,15 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             SYTRD_TICK(4);                                // Q accumulation
 
             // ---- everyone: full y -> LDS, y.v, w = y - (tau/2)(y.v) v
-            for (int i0 = tid, first = 1; (i0 < m || first) && ok; i0 += 8 * nthr, first = 0)        // ws = y for now
-                ok = sub8(yb, i0, nthr, m, tag, ws, err,
-                          (first && k >= 1 && tid < Ga && tid + ((n - 1 - tid) / G) * G <= k)    // workgroup `tid` has no column > k
-                              ? hg + (size_t)((k - 1) & 1) * G + tid : nullptr, step_tag(k - 1));
+            ok = sub_all(yb, m, tag, ws, err,                                  // ws = y for now
+                         (k >= 1 && tid < Ga && tid + ((n - 1 - tid) / G) * G <= k)    // workgroup `tid` has no column > k
+                             ? hg + (size_t)((k - 1) & 1) * G + tid : nullptr, step_tag(k - 1));
             double bad = ok ? 0.0 : 1.0, dot = 0.0;
             if (ok)
-                for (int i = tid; i < m; i += nthr) dot += ws[i] * vs[i];   // each thread re-reads only what it wrote
+                for (int i = 2 * tid; i < m; i += 2 * nthr) {               // each thread re-reads only what it wrote (sub_all)
+                    dot += ws[i] * vs[i];
+                    if (i + 1 < m) dot += ws[i + 1] * vs[i + 1];
+                }
             block_sum2(bad, dot, red, rs);
             if (bad != 0.0) return;
             if (tid == 0 && g + (nc - 1) * G <= k + 1)                      // from the step before my last y on:

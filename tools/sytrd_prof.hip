@@ -35,7 +35,7 @@ int main(int argc, char **argv)
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                           (u64 *)(w + 64) + 2 * (n + 1), (u64 *)(w + 64) + 2 * (n + 1) + 2 * n, (int *)(w + 8), withq ? dQ : nullptr);
+                           (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         u64 p[8]; hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sytrd_prof), sizeof(p));

@@ -61,6 +61,46 @@ __global__ void allgather(u64 *buf, int G, int stride, int per, int rounds, u64 
     if (tid == 0 && g == 0) out[0] = wall_clock64() - t0;
 }
 
+// Two granules per request: one 16-byte sc1 load per lane.  Each 8-byte half carries its own tag, so only a tear
+// INSIDE an aligned 8-byte half could hurt, and a 16-byte aligned lane access is served from one line read.
+__device__ __forceinline__ void load2(const u64 *p, u64 &a, u64 &b)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    a = ((u64)v.y << 32) | v.x;
+    b = ((u64)v.w << 32) | v.z;
+}
+
+__global__ void allgather_wide(u64 *buf, int G, int stride, int per, int rounds, u64 *out)
+{
+    if (blockIdx.x % stride != 0) return;
+    const int g = blockIdx.x / stride;
+    if (g >= G) return;
+    const int tid = threadIdx.x, total = G * per;
+    u64 t0 = wall_clock64();
+    for (int r = 1; r <= rounds; ++r) {
+        u64 *b = buf + (size_t)(r & 1) * total;
+        for (int i = tid; i < per; i += blockDim.x)
+            __hip_atomic_store(b + g * per + i, ((u64)r << 32) | (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 2 * tid; i < total; i += 2 * blockDim.x) {
+            u64 x = 0, y = 0;
+            u64 t_ = wall_clock64();
+            for (;;) {
+                load2(b + i, x, y);
+                // a granule is accepted on its LOW dword (where the sytrd tag lives): is the HIGH dword from the same store?
+                if ((unsigned)x == (unsigned)r && (x >> 32) != (u64)r) atomicAdd((unsigned long long *)(out + 4), 1ULL);
+                if ((unsigned)y == (unsigned)r && (y >> 32) != (u64)r) atomicAdd((unsigned long long *)(out + 4), 1ULL);
+                if ((unsigned)x == (unsigned)r && (unsigned)y == (unsigned)r) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t_ > 2000000ULL) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && g == 0) out[0] = wall_clock64() - t0;
+}
+
 int main()
 {
     u64 *flag, *out;
@@ -91,6 +131,17 @@ int main()
         hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
         printf("allgather %s G=%2d stride=%d (%s) %3d granules each (%d total): %.3f us per round\n", il ? "interleaved" : "contiguous ", c.G, c.stride,
                c.stride % 8 == 0 ? "one XCD" : "spread", c.per, c.G * c.per, (double)h[0] / 100.0 / rounds);
+    }
+    struct { int G, per; } wd[] = {{64, 8}, {64, 16}, {16, 32}, {8, 64}};
+    for (auto &c : wd) {
+        hipMemset(flag, 0, 1 << 20);
+        hipMemset(out, 0, 64);
+        hipLaunchKernelGGL(allgather_wide, dim3(c.G), dim3(256), 0, 0, flag, c.G, 1, c.per, rounds, out);
+        hipDeviceSynchronize();
+        u64 h[5];
+        hipMemcpy(h, out, 40, hipMemcpyDeviceToHost);
+        printf("allgather 16-byte polls     G=%2d spread %3d granules each (%d total): %.3f us per round, torn granules: %llu\n", c.G, c.per,
+               c.G * c.per, (double)h[0] / 100.0 / rounds, h[4]);
     }
     // (workgroup-scope (sc0) granules were tried here for participants on one XCD: the loads are served from the CU's
     //  L1 and never see the other CU's store - every spin ran into its timeout.  Agent scope is the only usable one.)
