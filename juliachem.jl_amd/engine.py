@@ -237,7 +237,8 @@ class DeviceSCF:
                         raise np.linalg.LinAlgError("non-finite DIIS coefficients")
                     cfull = np.zeros(nd)
                     cfull[order] = c
-                    F = (torch.as_tensor(cfull, device=F.device) @ self.F_hist).reshape(self.N, self.N)
+                    # sum_k c_k F_k as a GEMV on the transposed view (rocBLAS runs the (1 x nd)(nd x N^2) product as a 55 us GEMM)
+                    F = torch.mv(self.F_hist.t(), torch.as_tensor(cfull, device=F.device)).reshape(self.N, self.N)
                 except np.linalg.LinAlgError:                      # "Faulty DIIS!" SCF.jl:493-499
                     self.B_dim = 2
         self._mark("diis")
