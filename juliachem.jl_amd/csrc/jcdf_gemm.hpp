@@ -27,13 +27,11 @@ namespace jcdf {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// A_EXTRA: additional A columns (beyond the MFMA rows) staged into LDS for a VALU side
-// computation done by the `extra` hook (multiple of 2).
-template <int WM_, int WN_, int WAVES_M_, int WAVES_N_, int KC_, int A_EXTRA_ = 0>
+template <int WM_, int WN_, int WAVES_M_, int WAVES_N_, int KC_>
 struct GemmCfg {
     static constexpr int WM = WM_, WN = WN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, KC = KC_;
     static constexpr int TM_MFMA = 16 * WM * WAVES_M;
-    static constexpr int TM = TM_MFMA + A_EXTRA_;                 // staged A width
+    static constexpr int TM = TM_MFMA;                            // staged A width
     static constexpr int TN = 16 * WN * WAVES_N;
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
     static constexpr int LDAS = ((TM + 15) / 32) * 32 + 16;       // doubles; >= TM and stride*8 % 256 == 128
@@ -54,20 +52,13 @@ struct GemmCfg {
 // ABL: timing-only ablation bits for tools/w_ablate.hip (0 in the product):
 //   1 = no A global loads after the first stage, 2 = no B global loads after the first
 //   stage, 4 = no LDS re-staging (ds_write) after the first stage, 8 = no barrier in the loop.
-struct NoExtra {
-    __device__ __forceinline__ void operator()(const double *, const double *) const {}
-};
-
-// `extra(As, Bs)` is called once per LDS stage (KC rows; As row stride Cfg::LDAS, Bs row
-// stride Cfg::LDBS) between the MFMAs and the re-staging.
 // PREFETCH = 2: two register sets, every global load has two compute phases to land (for the
 // HBM-streaming W kernel); PREFETCH = 1: one set (operands served from L2, fewer VGPRs).
-template <class Cfg, bool STREAM_B, int ABL = 0, int PREFETCH = 1, class Extra = NoExtra>
+template <class Cfg, bool STREAM_B, int ABL = 0, int PREFETCH = 1>
 __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int64_t lda,
                                              const double *__restrict__ Bg, int64_t ldb,
                                              int nchunks, double4_t (&acc)[Cfg::WM][Cfg::WN],
-                                             double *smem, const int *__restrict__ klist = nullptr,
-                                             Extra extra = Extra())
+                                             double *smem, const int *__restrict__ klist = nullptr)
 {
     // klist (optional): stage t covers k rows [klist[t]*KC, +KC) instead of [t*KC, +KC) — block-sparse
     // contraction: all-zero stages (fully Schwarz-screened tiles) are simply not in the list.
@@ -150,7 +141,6 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
                 for (int n = 0; n < WN; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
         }
-        extra(smem + buf * Cfg::STAGE_DOUBLES, smem + buf * Cfg::STAGE_DOUBLES + KC * LDAS);
     };
 
     load_stage(ra0, rb0, 0);
