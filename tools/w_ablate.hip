@@ -160,8 +160,8 @@ int main(int argc, char **argv)
         hipFuncSetAttribute((const void *)k_exchange_W<6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
         const int nnt = Np / Cfg::TN;
         const int nblk = ((Ql * nnt + 7) / 8) * 8;
-        vs.push_back({"PRODUCT k_exchange_W<6> without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, 1, false>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
-        vs.push_back({"PRODUCT k_exchange_W<6>", [=] { hipLaunchKernelGGL((k_exchange_W<6>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt); }, {}});
+        vs.push_back({"PRODUCT k_exchange_W<6> without fused V", [=] { hipLaunchKernelGGL((k_exchange_W<6, 1, false>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt, (const int *)nullptr, (const int *)nullptr); }, {}});
+        vs.push_back({"PRODUCT k_exchange_W<6>", [=] { hipLaunchKernelGGL((k_exchange_W<6>), dim3(nblk), dim3(256), Cfg::SMEM_BYTES, 0, B, C, C, W, vp, Ql, o, Nk, Np, opad, 1, nnt, (const int *)nullptr, (const int *)nullptr); }, {}});
     }
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>; using I15 = std::integral_constant<int, 15>;
