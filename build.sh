@@ -8,6 +8,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread \
     -Wall -Wno-unused-function \
     -I"$ROOT/include" \
-    "$PKG/csrc/jcdf_api.hip" -o "$PKG/lib/libjcdf_hip.so" "$@"
+    "$PKG/csrc/jcdf_api.hip" "$PKG/csrc/jcint_host.cpp" -o "$PKG/lib/libjcdf_hip.so" "$@"
 gcc -O2 -fPIC -shared -o "$ROOT/oracle/_build/libjcdf_oracle.so" "$ROOT/oracle/c/jcdf_oracle.c"
 echo "built: $PKG/lib/libjcdf_hip.so  $ROOT/oracle/_build/libjcdf_oracle.so"

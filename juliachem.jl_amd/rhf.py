@@ -1,0 +1,90 @@
+"""`JCRHF.Energy.run` for the density-fitted GPU path, end to end inside this package (reference:
+src/rhf/energy/Energy.jl:35-85 -> rhf_energy / rhf_kernel, SCF.jl:60-260): host integrals (include/jcint.h),
+Schwarz screening + packed layout (SchwarzScreening.jl:9-83), B formation and the Fock build on the device(s)
+(include/jcdf.h), SCF loop on the device (engine.py).  One process per GPU; under torch.distributed every rank
+computes the three-centre integrals of its own auxiliary shard only (GPUDF.jl:51-57).
+
+The basis is passed as data (symbol -> shells), see integrals.py; everything else follows the reference's
+`keywords.scf` flags (SCFOptions.jl) and returns the reference's result dictionary (SCF.jl:251-258)."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .df import (JCTC, create_jctiming, create_scf_options, get_screening_metadata, packed_pq_lists)
+from .integrals import HostIntegralEngine
+
+
+def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[Dict]], aux_basis: Dict[str, List[Dict]],
+        scf_flags: Optional[Dict[str, Any]] = None, molecular_charge: int = 0, output: int = 0,
+        device: Optional[int] = None) -> Dict[str, Any]:
+    import time
+    import torch
+    from .engine import DeviceFockBuilder, DeviceSCF
+
+    flags = dict(scf_flags or {})
+    flags.setdefault("scf_type", "df")
+    flags.setdefault("contraction_mode", "GPU")
+    opts = create_scf_options(flags)
+    if not opts.density_fitting or opts.contraction_mode not in ("GPU", "HIP", "denseGPU"):
+        raise ValueError("rhf.run: only scf_type 'df' with a GPU contraction mode is implemented (no CPU path in this package)")
+    if opts.guess != "hcore":
+        raise ValueError("rhf.run: guess 'hcore' only (SAD / conventional guesses stay with the reference host code)")
+    jc_timing = create_jctiming()
+    t_all = time.perf_counter()
+    eng = HostIntegralEngine(atoms, basis, aux_basis, charges)
+    N, Q = eng.prim.nbf, eng.aux.nbf
+    nels = int(round(float(np.sum(eng.Z)))) - int(molecular_charge)
+    if nels % 2:
+        raise ValueError("rhf.run: closed-shell RHF needs an even number of electrons")
+    n_occ = nels // 2
+    S, T, V = eng.one_electron()
+    H = T + V
+    E_nuc = eng.nuclear_repulsion()
+    t0 = time.perf_counter()
+    J2c = eng.calculate_two_center_intgrals()                              # GPUDF.jl:43
+    jc_timing.timings[JCTC.two_eri_time] = time.perf_counter() - t0
+    # dense below 800 functions on a single rank, packed/screened otherwise (DensityFitting.jl:78-90)
+    world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+    dense = opts.contraction_mode == "denseGPU" or opts.df_force_dense or (opts.df_use_adaptive and N < 800 and world == 1)
+    sd, pq = None, (None, None)
+    if not dense:
+        t0 = time.perf_counter()
+        mask = eng.schwarz_mask(opts.df_screening_sigma, float(np.max(np.diag(J2c))))     # ScreenedDF.jl:16-77
+        sd = get_screening_metadata(mask)
+        pq = packed_pq_lists(sd)
+        jc_timing.timings[JCTC.screening_time] = time.perf_counter() - t0
+        jc_timing.non_timing_data[JCTC.screened_indices_count] = str(int(mask.sum()))
+    fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq)
+    fb.set_metric(J2c)
+    fb.set_core_hamiltonian(H)
+    t0 = time.perf_counter()
+    T_own = eng.calculate_three_center_integrals(fb.rows, sd)              # (rows, P) column-major, this rank's shard
+    jc_timing.timings[JCTC.three_eri_time] = time.perf_counter() - t0
+    fb.exchange_three_center(torch.as_tensor(np.ravel(T_own, order="K"), device=fb.device))
+    del T_own
+    scf = DeviceSCF(fb, H, S, E_nuc)
+    converged = False
+    E = 0.0
+    it = 0
+    for it in range(1, opts.df_max_iterations + 1):                         # SCF.jl:399-573, 596-604
+        E, dE, drms = scf.step()
+        if output >= 2 and fb.rank == 0:
+            print("%d      %.10f      %.10f      %.10f" % (it, E, dE, drms))
+        if abs(dE) <= opts.df_energy_convergence and drms <= opts.df_density_convergence:
+            converged = True
+            break
+    eps = scf.eps.cpu().numpy()
+    C = scf.C.cpu().numpy()
+    Cocc = C[:, :n_occ]
+    W = 2.0 * (Cocc * eps[:n_occ][None, :]) @ Cocc.T                         # energy-weighted density, SCF.jl:262-275
+    jc_timing.run_time = time.perf_counter() - t_all
+    jc_timing.converged, jc_timing.scf_energy = converged, E          # set_converge_properties!, SCF.jl:588
+    jc_timing.non_timing_data[JCTC.contraction_algorithm] = "dense hip" if dense else "screened hip"
+    out = {"Fock": scf.F.cpu().numpy(), "Density": scf.D.cpu().numpy(), "Energy-Weighted Density": W, "MO Coeff": C,
+           "Overlap": S, "Energy": E, "Converged?": converged, "Timings": jc_timing,
+           "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail)}
+    fb.close()
+    eng.close()
+    return out

@@ -565,3 +565,25 @@ def test_device_stedc_matches_lapack(name, d, e):
     assert np.abs(w - wref).max() / sc < tol
     assert np.abs(V.T @ V - np.eye(n)).max() < tol
     assert np.abs(T @ V - V * w[None, :]).max() / sc < tol
+
+
+# ---- end to end inside the package: host integrals (jcint) -> screening -> device B and SCF (rhf.run) ----------
+@pytest.mark.parametrize("case,flags,tol", [("ccpvdz", {}, 1e-9), ("ccpvdz", {"df_use_adaptive": False}, 1e-9),
+                                            ("631g2dfp", {"niter": 20}, 1e-7)])
+def test_rhf_run_reproduces_reference_energies(case, flags, tol):
+    """`rhf.run` (the package's JCRHF.Energy.run for the DF GPU path: library integrals, Schwarz screening, packed
+    layout, device Cholesky, HIP Fock build, device SCF) on the reference's two golden water runs, dense and
+    screened: final energy and iteration count of the reference's own logs."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES[case])))
+    f = dict({"dele": 1e-6, "rmsd": 1e-6, "niter": 50}, **flags)
+    res = rhf.run(g["atoms"], g["charges"], g["basis"], g["aux_basis"], f)
+    assert res["Converged?"]
+    assert abs(res["Energy"] - g["final_energy"]) < tol, res["Energy"]
+    assert res["Iterations"] == (len(g["trail"]) + 1 if case == "ccpvdz" else len(g["trail"]))
+    assert res["Timings"].non_timing_data["contraction_algorithm"] == ("screened hip" if flags.get("df_use_adaptive") is False else "dense hip")
+    n = res["Overlap"].shape[0]
+    assert np.allclose(res["MO Coeff"].T @ res["Overlap"] @ res["MO Coeff"], np.eye(n), atol=1e-9)
+    assert abs(np.trace(res["Density"] @ res["Overlap"]) - 10.0) < 1e-9            # 10 electrons

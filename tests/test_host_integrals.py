@@ -1,0 +1,90 @@
+"""The library's host integral engine (include/jcint.h) against the oracle's independent
+numpy McMurchie-Davidson code on the two golden water cases (d, f, g functions, sp shells), and its Schwarz data
+against integrals it produces another way.  No GPU needed: the engine is host code of libjcdf_hip.so.
+(The oracle's integrals are themselves pinned by the reference's golden SCF trails, test_oracle_golden_water.py.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import juliachem_jl_amd as jc
+from juliachem_jl_amd.integrals import HostIntegralEngine
+from water_case import water, GOLDEN, FIXTURES
+
+
+def _engine(case):
+    d = json.load(open(os.path.join(GOLDEN, FIXTURES[case])))
+    return HostIntegralEngine(d["atoms"], d["basis"], d["aux_basis"], d["charges"]), d
+
+
+@pytest.mark.parametrize("case", ["ccpvdz", "631g2dfp"])
+def test_engine_matches_oracle_integrals(case):
+    eng, d = _engine(case)
+    w = water(case)
+    N, Q = w["S"].shape[0], w["J2c"].shape[0]
+    assert eng.prim.nbf == N and eng.aux.nbf == Q
+    assert eng.prim.shell_nbas == w["prim_shell_nbas"] and eng.aux.shell_nbas == w["aux_shell_nbas"]
+    S, T, V = eng.one_electron()
+    assert np.abs(S - w["S"]).max() < 1e-13
+    assert np.abs(T + V - w["H"]).max() < 1e-11 * np.abs(w["H"]).max()
+    assert abs(eng.nuclear_repulsion() - w["E_nuc"]) < 1e-13
+    J = eng.calculate_two_center_intgrals()
+    assert np.all(np.triu(J, 1) == 0.0)                              # lower triangle only, like the reference
+    assert np.abs(J - np.tril(w["J2c"])).max() < 1e-12 * np.abs(w["J2c"]).max()
+    T3 = eng.calculate_three_center_integrals(range(0, Q), None)     # dense map c = q + N p
+    ref = np.asfortranarray(w["T3"].reshape(Q, N * N, order="F"))
+    assert np.abs(T3 - ref).max() < 1e-12 * np.abs(ref).max()
+    eng.close()
+
+
+def test_three_center_shards_and_packed_layout():
+    """A shard of auxiliary shells in the packed (Schwarz) layout == the same rows/columns of the dense tensor."""
+    eng, d = _engine("ccpvdz")
+    w = water("ccpvdz")
+    N, Q = 25, 96
+    rng = np.random.default_rng(3)
+    mask = rng.random((N, N)) < 0.6
+    mask = mask | mask.T | np.eye(N, dtype=bool)
+    sd = jc.get_screening_metadata(mask)
+    pq_p, pq_q = jc.packed_pq_lists(sd)
+    pos = eng.aux.shell_pos
+    q0, q1 = int(pos[5]), int(pos[17])
+    T = eng.calculate_three_center_integrals(range(q0, q1), sd)
+    assert T.shape == (q1 - q0, len(pq_p))
+    assert np.abs(T - w["T3"][q0:q1][:, pq_q, pq_p]).max() < 1e-13
+    with pytest.raises(jc.JCDFError):                                # a range that cuts a shell
+        eng.calculate_three_center_integrals(range(int(pos[8]) + 1, q1), sd)      # shell 8 is a p shell
+    eng.close()
+
+
+def test_schwarz_data_and_mask():
+    """(pq|pq) from the engine's 4-centre path: positive, bounded by Cauchy-Schwarz on the fitted integrals, and for
+    s functions on one centre equal to the closed form; the mask follows SchwarzScreening.jl:9-71."""
+    eng, d = _engine("ccpvdz")
+    w = water("ccpvdz")
+    M, sh = eng.schwarz_data()
+    assert np.all(M >= -1e-14) and np.allclose(M, M.T)
+    # DF is a projection in the Coulomb metric: sum_Q B_Q(pq)^2 <= (pq|pq), tight for a good fitting basis
+    from oracle import df_fock as orc
+    B = orc.calculate_B(w["J2c"], w["T3"])
+    fitted = np.einsum("Qpq,Qpq->pq", B, B)
+    assert np.all(fitted <= M * (1 + 1e-10) + 1e-12)
+    assert np.abs(fitted - M).max() < 1e-2 * M.max()                  # the RI fitting error of (pq|pq) itself
+    # (ss|ss) of one normalised primitive s Gaussian with exponent a: 2 sqrt(a / pi)
+    a = 0.7
+    one = HostIntegralEngine([{"symbol": "X", "center": [0, 0, 0]}], {"X": [{"l": 0, "exps": [a], "coefs": [1.0]}]},
+                             {"X": [{"l": 0, "exps": [a], "coefs": [1.0]}]}, {"X": 1.0})
+    assert abs(one.schwarz_data()[0][0, 0] - 2.0 * np.sqrt(a / np.pi)) < 1e-14
+    one.close()
+    # the mask: nothing screened at the reference's default sigma for a single water molecule ...
+    maxPP = np.max(np.diag(w["J2c"]))
+    assert eng.schwarz_mask(1e-5, maxPP).all()
+    # ... and a huge sigma screens exactly the pairs below the threshold
+    sig = 0.5
+    thr = sig * sig / maxPP
+    mask = eng.schwarz_mask(sig, maxPP)
+    idx = np.repeat(np.arange(eng.prim.nshell), eng.prim.shell_nbas)
+    expect = (np.abs(sh)[np.ix_(idx, idx)] >= thr) & (np.abs(M) >= thr)
+    assert np.array_equal(mask, expect) and not mask.all() and mask.any()
+    eng.close()

@@ -19,6 +19,18 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(jcdf_[a-z_0-9A-Z]+)\s*\(", txt)) - {"jcdf_status"})
 
 
+def test_library_exports_every_symbol_of_jcint_h():
+    """include/jcint.h (host integral engine): every declared entry is exported and bound by the Python mirror."""
+    from juliachem_jl_amd import integrals
+    txt = open(os.path.join(ROOT, "include", "jcint.h")).read()
+    names = sorted(set(re.findall(r"\b(jcint_[a-z_0-9A-Z]+)\s*\(", txt)))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+        assert n in integrals._PROTOS, "no ctypes prototype for %s" % n
+
+
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     names = _declared_symbols()
