@@ -587,3 +587,44 @@ def test_rhf_run_reproduces_reference_energies(case, flags, tol):
     n = res["Overlap"].shape[0]
     assert np.allclose(res["MO Coeff"].T @ res["Overlap"] @ res["MO Coeff"], np.eye(n), atol=1e-9)
     assert abs(np.trace(res["Density"] @ res["Overlap"]) - 10.0) < 1e-9            # 10 electrons
+
+
+def test_rhf_run_water_dimer_screened_equals_dense():
+    """A water dimer 7 bohr apart: the Schwarz mask really drops pairs (packed layout, block-sparse W/J); the screened
+    energy agrees with the dense one to the screening error, and both with the CPU oracle's dense SCF on the oracle's
+    own integrals."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    from oracle import integrals as gi, scf as oscf
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
+                                for a in g["atoms"]]
+    f = {"dele": 1e-8, "rmsd": 1e-8, "niter": 60}
+    dense = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], f)
+    scr = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], dict(f, df_use_adaptive=False))
+    assert dense["Converged?"] and scr["Converged?"]
+    kept = int(scr["Timings"].non_timing_data["screened_indices_count"])
+    assert kept < 50 * 50                                                   # something was screened
+    assert abs(dense["Energy"] - scr["Energy"]) < 1e-6                     # the screening error of sigma = 1e-5 itself (2.8e-7 here)
+    prim = gi.build_shells(atoms, g["basis"]); aux = gi.build_shells(atoms, g["aux_basis"])
+    Z = [g["charges"][a["symbol"]] for a in atoms]; R = np.array([a["center"] for a in atoms])
+    S, T, V = gi.one_electron(prim, Z, R)
+    B = orc.calculate_B(gi.two_center(aux), gi.three_center(aux, prim))
+    ref = oscf.rhf_df_scf(T + V, S, gi.nuclear_repulsion(Z, R), 10, lambda C, it: T + V + orc.df_rhf_fock_build_BLAS(B, C[:, :10]),
+                          dele=1e-8, rmsd=1e-8, niter=60)
+    assert ref.converged and abs(dense["Energy"] - ref.energy) < 1e-9
+    assert dense["Iterations"] == ref.iterations
+    # the screened run against the oracle's screened algorithm with the same Schwarz mask: parity, not screening error
+    from juliachem_jl_amd.integrals import HostIntegralEngine
+    eng = HostIntegralEngine(atoms, g["basis"], g["aux_basis"], g["charges"])
+    J2 = gi.two_center(aux)
+    mask = eng.schwarz_mask(1e-5, float(np.max(np.diag(J2))))
+    eng.close()
+    assert int(mask.sum()) == kept
+    sd = orc.get_screening_metadata(mask)
+    Bp = orc.pack_three_center(B, sd)
+    H = T + V
+    ref_s = oscf.rhf_df_scf(H, S, gi.nuclear_repulsion(Z, R), 10, lambda C, it: H + orc.df_rhf_fock_build_screened(Bp, C[:, :10], sd),
+                            dele=1e-8, rmsd=1e-8, niter=60)
+    assert ref_s.converged and abs(scr["Energy"] - ref_s.energy) < 1e-9 and scr["Iterations"] == ref_s.iterations

@@ -88,3 +88,39 @@ def test_schwarz_data_and_mask():
     expect = (np.abs(sh)[np.ix_(idx, idx)] >= thr) & (np.abs(M) >= thr)
     assert np.array_equal(mask, expect) and not mask.all() and mask.any()
     eng.close()
+
+
+def _dimer(sep=7.0):
+    d = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = list(d["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + sep, a["center"][2] + 1.1]}
+                                for a in d["atoms"]]
+    return atoms, d
+
+
+def test_engine_matches_oracle_on_a_water_dimer():
+    """Two waters 7 bohr apart: long-range integrals (large Boys arguments, the asymptotic branch) and a Schwarz
+    mask that really screens.  Oracle comparison on (P|Q), S, H and the three-centre rows of a few auxiliary shells."""
+    from oracle import integrals as gi
+    atoms, d = _dimer()
+    eng = HostIntegralEngine(atoms, d["basis"], d["aux_basis"], d["charges"])
+    prim = gi.build_shells(atoms, d["basis"]); aux = gi.build_shells(atoms, d["aux_basis"])
+    Z = [d["charges"][a["symbol"]] for a in atoms]; R = np.array([a["center"] for a in atoms])
+    S, T, V = eng.one_electron()
+    So, To, Vo = gi.one_electron(prim, Z, R)
+    assert np.abs(S - So).max() < 1e-13 and np.abs(T - To).max() < 1e-11 and np.abs(V - Vo).max() < 1e-10
+    J = eng.calculate_two_center_intgrals()
+    assert np.abs(J - np.tril(gi.two_center(aux))).max() < 1e-12 * np.abs(J).max()
+    N = eng.prim.nbf
+    pos = eng.aux.shell_pos
+    for s0, s1 in ((0, 3), (40, 43)):                                  # a few shells of the first and of the second molecule
+        q0, q1 = int(pos[s0]), int(pos[s1])
+        T3 = eng.calculate_three_center_integrals(range(q0, q1), None)
+        ref = gi.three_center(aux[s0:s1], prim)
+        assert np.abs(T3 - ref.reshape(q1 - q0, N * N, order="F")).max() < 1e-12
+    # screening: with the reference's default sigma pairs between the two molecules' tight functions are dropped
+    mask = eng.schwarz_mask(1e-5, float(np.max(np.diag(J))))
+    assert mask.sum() < N * N and np.array_equal(mask, mask.T) and mask.diagonal().all()
+    M, _ = eng.schwarz_data()
+    T_all = eng.calculate_three_center_integrals(range(0, int(pos[6])), None).reshape(-1, N, N, order="F")
+    assert np.abs(T_all[:, ~mask]).max() < 1e-5                        # what is screened is below sigma: |(P|pq)| <= sqrt((P|P)(pq|pq))
+    eng.close()
