@@ -59,11 +59,31 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq)
     fb.set_metric(J2c)
     fb.set_core_hamiltonian(H)
-    t0 = time.perf_counter()
-    T_own = eng.calculate_three_center_integrals(fb.rows, sd)              # (rows, P) column-major, this rank's shard
-    jc_timing.timings[JCTC.three_eri_time] = time.perf_counter() - t0
-    fb.exchange_three_center(torch.as_tensor(np.ravel(T_own, order="K"), device=fb.device))
-    del T_own
+    t_eri = 0.0
+    if fb.world == 1:
+        # one rank: stream the auxiliary shells through in blocks of <= `block` functions, so the host never holds
+        # more than one (block x P) slab of the three-centre tensor (ThreeCenterIntegralsScreened.jl:8-85 fills the
+        # whole (A, P) array; (H2O)50: 9 GB packed, 60 GB dense)
+        pos = eng.aux.shell_pos
+        block = int(flags.get("three_center_block", 512))
+        s0 = 0
+        while s0 < eng.aux.nshell:
+            s1 = s0 + 1
+            while s1 < eng.aux.nshell and pos[s1 + 1] - pos[s0] <= block:
+                s1 += 1
+            t0 = time.perf_counter()
+            Tb = eng.calculate_three_center_integrals(range(int(pos[s0]), int(pos[s1])), sd)
+            t_eri += time.perf_counter() - t0
+            fb.push_three_center_device(int(pos[s0]), int(pos[s1]), torch.as_tensor(np.ravel(Tb, order="K"), device=fb.device))
+            torch.cuda.synchronize(fb.device)
+            s0 = s1
+    else:
+        t0 = time.perf_counter()
+        T_own = eng.calculate_three_center_integrals(fb.rows, sd)          # (rows, P) column-major, this rank's shard
+        t_eri = time.perf_counter() - t0
+        fb.exchange_three_center(torch.as_tensor(np.ravel(T_own, order="K"), device=fb.device))
+        del T_own
+    jc_timing.timings[JCTC.three_eri_time] = t_eri
     scf = DeviceSCF(fb, H, S, E_nuc)
     converged = False
     E = 0.0
