@@ -16,6 +16,24 @@ from .df import (JCTC, create_jctiming, create_scf_options, get_screening_metada
 from .integrals import HostIntegralEngine
 
 
+def spatial_order(atoms: Sequence[Dict], cell: float = 4.0) -> List[int]:
+    """Atom order along a Z-order (Morton) curve through cells of `cell` bohr.  The library keeps B dense-with-zeros and
+    skips whole 16 x 128 tiles without a kept (q, p) pair (jcdf_configure); with atoms in arbitrary input order the
+    Schwarz-kept pairs are scattered over the whole index space and no tile is empty, with neighbours adjacent they
+    gather around the diagonal.  Energies do not depend on the order; results are returned in the caller's order."""
+    R = np.asarray([a["center"] for a in atoms], dtype=np.float64)
+    q = np.floor((R - R.min(axis=0)) / cell).astype(np.int64)
+
+    def morton(v):
+        code = 0
+        for bit in range(16):
+            for d in range(3):
+                code |= ((int(v[d]) >> bit) & 1) << (3 * bit + d)
+        return code
+    keys = [morton(v) for v in q]
+    return sorted(range(len(atoms)), key=lambda i: (keys[i], i))
+
+
 def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[Dict]], aux_basis: Dict[str, List[Dict]],
         scf_flags: Optional[Dict[str, Any]] = None, molecular_charge: int = 0, output: int = 0,
         device: Optional[int] = None) -> Dict[str, Any]:
@@ -33,6 +51,14 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
         raise ValueError("rhf.run: guess 'hcore' only (SAD / conventional guesses stay with the reference host code)")
     jc_timing = create_jctiming()
     t_all = time.perf_counter()
+    # spatial atom order for the screened layout (see spatial_order); `ao_back` maps the internal AO order to the caller's
+    user_atoms = list(atoms)
+    order = spatial_order(user_atoms) if flags.get("reorder_atoms", True) else list(range(len(user_atoms)))
+    atoms = [user_atoms[i] for i in order]
+    nb_atom = [sum((sh["l"] + 1) * (sh["l"] + 2) // 2 for sh in basis[a["symbol"]]) for a in user_atoms]
+    start = np.concatenate([[0], np.cumsum(nb_atom)])
+    ao_internal = np.concatenate([np.arange(start[i], start[i + 1]) for i in order]).astype(np.int64)   # internal k -> user AO
+    ao_back = np.argsort(ao_internal)                                                                 # user AO -> internal k
     eng = HostIntegralEngine(atoms, basis, aux_basis, charges)
     N, Q = eng.prim.nbf, eng.aux.nbf
     nels = int(round(float(np.sum(eng.Z)))) - int(molecular_charge)
@@ -102,9 +128,12 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     jc_timing.run_time = time.perf_counter() - t_all
     jc_timing.converged, jc_timing.scf_energy = converged, E          # set_converge_properties!, SCF.jl:588
     jc_timing.non_timing_data[JCTC.contraction_algorithm] = "dense hip" if dense else "screened hip"
-    out = {"Fock": scf.F.cpu().numpy(), "Density": scf.D.cpu().numpy(), "Energy-Weighted Density": W, "MO Coeff": C,
-           "Overlap": S, "Energy": E, "Converged?": converged, "Timings": jc_timing,
-           "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail)}
+    u = ao_back                                                            # back to the caller's AO order
+    sym = lambda M: np.ascontiguousarray(M[np.ix_(u, u)])
+    out = {"Fock": sym(scf.F.cpu().numpy()), "Density": sym(scf.D.cpu().numpy()), "Energy-Weighted Density": sym(W),
+           "MO Coeff": np.ascontiguousarray(C[u, :]), "Overlap": sym(S), "Energy": E, "Converged?": converged, "Timings": jc_timing,
+           "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail),
+           "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes()}
     fb.close()
     eng.close()
     return out

@@ -26,3 +26,5 @@ print("wall %.1f s: two-centre %.2f s, Schwarz + packing %.2f s (kept pairs %s o
     tm.timings.get("three_eri_time", 0.0)))
 eps = res["Orbital Energies"]; o = 5 * nw
 print("HOMO %.6f  LUMO %.6f  gap %.6f Eh" % (eps[o - 1], eps[o], eps[o] - eps[o - 1]))
+print("last Fock build: " + ", ".join("%s %.2f ms" % (k["name"], 1e3 * k["seconds"]) for k in res["Kernel Stats"]) +
+      "; device memory %.1f GB" % (res["Device Bytes"] / 1e9))
