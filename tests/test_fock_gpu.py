@@ -628,3 +628,48 @@ def test_rhf_run_water_dimer_screened_equals_dense():
     ref_s = oscf.rhf_df_scf(H, S, gi.nuclear_repulsion(Z, R), 10, lambda C, it: H + orc.df_rhf_fock_build_screened(Bp, C[:, :10], sd),
                             dele=1e-8, rmsd=1e-8, niter=60)
     assert ref_s.converged and abs(scr["Energy"] - ref_s.energy) < 1e-9 and scr["Iterations"] == ref_s.iterations
+
+
+def _rhf_rank(rank, world, port, out):
+    import json, os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from juliachem_jl_amd import rhf
+        from water_case import GOLDEN, FIXTURES
+        g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+        atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
+                                    for a in g["atoms"]]
+        res = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], {"dele": 1e-8, "rmsd": 1e-8, "niter": 60}, device=0)
+        out.put((rank, res["Energy"], res["Iterations"], res["Timings"].non_timing_data["contraction_algorithm"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rhf_run_two_ranks_on_one_gpu():
+    """Two processes (gloo rehearsal of the RCCL job, both on the one GPU of the box): every rank computes the
+    three-centre integrals of its own auxiliary shard only, blocks are exchanged, F is all-reduced; multi-rank runs take
+    the screened layout (DensityFitting.jl:78-90).  Same energy as the single-rank screened run."""
+    import socket
+    import torch.multiprocessing as mp
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    import json, os
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rhf_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(2))
+    assert got[0][1:] == got[1][1:] and got[0][3] == "screened hip"         # identical on both ranks
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
+                                for a in g["atoms"]]
+    one = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], {"dele": 1e-8, "rmsd": 1e-8, "niter": 60, "df_use_adaptive": False})
+    assert abs(got[0][1] - one["Energy"]) < 1e-9 and got[0][2] == one["Iterations"]
