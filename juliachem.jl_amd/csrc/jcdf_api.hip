@@ -1028,6 +1028,17 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 2 * (n + 2), *hg = yg + 2 * ((n + 1) & ~(int64_t)1);
     // tags restart at 1 every call: all granules (and the error word) are zeroed first
     if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
+    // one exchange per column (every workgroup forms the reflector itself) wins while the redundant work is small:
+    // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
+    static const int onehop_env = getenv("JCDF_SYTRD_ONEHOP") ? atoi(getenv("JCDF_SYTRD_ONEHOP")) : -1;
+    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 640;
+    if (onehop && lds + (size_t)3 * n * 8 <= 160 * 1024) {
+        const size_t lds1 = lds + (size_t)3 * n * 8;
+        (void)hipFuncSetAttribute((const void *)k_sytrd_onehop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipLaunchKernelGGL(k_sytrd_onehop, dim3((unsigned)G), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
+                           hg, err, d_Q);
+        return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+    }
     (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
                        hg, err, d_Q);

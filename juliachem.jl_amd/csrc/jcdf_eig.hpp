@@ -436,4 +436,218 @@ __global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int
             for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * n + i] = qrow[(size_t)r * n + i];
 }
 
+// ---- the same, two buffers polled together (one round trip): pairs of both, + optional heartbeat ---------------
+__device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *dst1, const u64 *g2, unsigned tag2, double *dst2,
+                                        int count, int *err, const u64 *beat, unsigned btag)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    bool ok = true;
+    for (int i0 = 2 * tid, first = 1; (i0 < count || first) && ok; i0 += 2 * nthr, first = 0) {
+        unsigned pending = (first && beat) ? 16u : 0u;
+        if (i0 < count) pending |= 1u | (g2 ? 4u : 0u);
+        if (i0 + 1 < count) pending |= 2u | (g2 ? 8u : 0u);
+        unsigned spins = 0;
+        u64 t0 = 0;
+        while (pending) {
+            const u64 a0 = (pending & 1u) ? __hip_atomic_load(g1 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const u64 a1 = (pending & 2u) ? __hip_atomic_load(g1 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const u64 b0 = (pending & 4u) ? __hip_atomic_load(g2 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const u64 b1 = (pending & 8u) ? __hip_atomic_load(g2 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const u64 hb = (pending & 16u) ? __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            if ((pending & 1u) && (unsigned)(a0 & 3ULL) == tag1) { dst1[i0] = __longlong_as_double((long long)(a0 & ~3ULL)); pending &= ~1u; }
+            if ((pending & 2u) && (unsigned)(a1 & 3ULL) == tag1) { dst1[i0 + 1] = __longlong_as_double((long long)(a1 & ~3ULL)); pending &= ~2u; }
+            if ((pending & 4u) && (unsigned)(b0 & 3ULL) == tag2) { dst2[i0] = __longlong_as_double((long long)(b0 & ~3ULL)); pending &= ~4u; }
+            if ((pending & 8u) && (unsigned)(b1 & 3ULL) == tag2) { dst2[i0 + 1] = __longlong_as_double((long long)(b1 & ~3ULL)); pending &= ~8u; }
+            if ((pending & 16u) && (unsigned)(hb & 3ULL) == btag) pending &= ~16u;
+            if (!pending) break;
+            if (!spin_ok(spins, t0, err)) { ok = false; break; }
+        }
+    }
+    return ok;
+}
+
+// ---- k_sytrd_onehop: ONE all-to-all exchange per column (experimental twin of k_sytrd_lower, same interface) -----
+// At step k every workgroup holds v_k, tau_k and has published y_k = tau_k A v_k for its own columns.  Then
+//   a. (while y travels) Q <- Q H_k on its rows of Q;
+//   b. it takes column k+1 (state before update k), which its owner broadcast ONE STEP AHEAD, together with
+//   c. the full y_k (+ heartbeats), forms y.v and w = y - (tau/2)(y.v) v itself;
+//   d. it applies update k to its copy of column k+1 and forms the reflector v_{k+1}, tau_{k+1} itself — every
+//      workgroup runs the same instructions on the same bits, so all copies are identical and the reflector never
+//      travels; the owner also keeps it in LAPACK storage;
+//   e. ONE pass over its columns j > k+1: A[:, j] -= v w_j + w v_j fused with y_{k+1,j} = tau A[:, j].v_{k+1},
+//      published at once; the owner of column k+2 broadcasts that column (now in the state step k+1 needs).
+// Buffers (parity of the item index), tags and the heartbeat rule as in k_sytrd_lower; here the heartbeat (k) is
+// fresh: a workgroup with no column > k publishes it where the others publish y_k.
+// LDS: ((Qout ? 2 : 1) * ncol_max * n + 5 n + 32) doubles.
+__global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
+                                                      double *__restrict__ E, double *__restrict__ TAU,
+                                                      u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int ncol_max = (n + G - 1) / G;
+    const int nc = (n - g + G - 1) / G > 0 ? (n - g + G - 1) / G : 0;       // my columns: g, g+G, ...
+    const int Ga = n < G ? n : G;
+    if (nc == 0) return;
+    const int lastcol = g + (nc - 1) * G;
+    double *slab = lds;
+    double *vs = lds + (size_t)ncol_max * n;              // v_k      (index 0 <-> row k+1)
+    double *vnext = vs + n;                               // v_{k+1}  (index 0 <-> row k+2)
+    double *ys = vnext + n;                               // y_k
+    double *ws = ys + n;                                  // w_k
+    double *cs = ws + n;                                  // column k+1, then x = that column after update k
+    double *red = cs + n;
+    double *qrow = red + 32;
+    unsigned rs = 0;
+    const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;
+    const int ne = (n + 1) & ~1, nv = n + 2;              // buffer strides (even)
+    if (Qout)
+        for (int r = 0; r < nc; ++r)
+            for (int i = tid; i < n; i += nthr) qrow[(size_t)r * n + i] = (i == g + r * G) ? 1.0 : 0.0;
+    for (int c = 0; c < nc; ++c)
+        for (int i = tid; i < n; i += nthr) slab[(size_t)c * n + i] = A[(size_t)(g + c * G) * lda + i];
+    for (int i = tid; i < n; i += nthr) vs[i] = ws[i] = 0.0;                // "update -1" is empty
+    __syncthreads();
+    if (g == 0)                                           // column 0 as it is; column 1 goes out in the first fused pass
+        for (int i = tid; i < n; i += nthr) pub(cg, i, slab[i], step_tag(0));
+
+#ifdef JCDF_SYTRD_PROFILE
+    u64 tprof = wall_clock64();
+#endif
+    double tau = 0.0;
+    for (int k = -1; k < n - 1; ++k) {
+        const int r0 = k + 1, m = n - r0;                 // rows r0 .. n-1, relative index i <-> row r0 + i
+        // ---- a. while y_k travels: Q <- Q H_k on my rows of Q
+        if (Qout && k >= 0) {
+            for (int rb = 0; rb < nc; rb += cpp) {
+                const bool have = rb + ce < nc;
+                double *q = qrow + (size_t)(have ? rb + ce : 0) * n + r0;
+                double s0 = 0.0, s1 = 0.0;
+                int i = seg;
+                for (; i + 32 < m; i += 64) {
+                    s0 += q[i] * vs[i];
+                    s1 += q[i + 32] * vs[i + 32];
+                }
+                if (i < m) s0 += q[i] * vs[i];
+                const double h = half_sums(s0 + s1);
+                const long long hb_ = __double_as_longlong(h);
+                const int lo31 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 31);
+                const int lo63 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 63);
+                const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
+                                              : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
+                const double sc = tau * tot;
+                if (have)
+                    for (int i2 = seg; i2 < m; i2 += 32) q[i2] -= sc * vs[i2];
+            }
+        }
+        SYTRD_TICK(4);                                    // Q accumulation
+        // ---- b + c. column r0 and y_k (+ heartbeat of the workgroups without a column > k), ONE round of polls
+        const u64 *cb = cg + (size_t)(r0 & 1) * nv;
+        const u64 *yb = k >= 0 ? yg + (size_t)(k & 1) * ne : nullptr;
+        const u64 *hb = (k >= 0 && tid < Ga && tid + ((n - 1 - tid) / G) * G <= k) ? hg + (size_t)(k & 1) * G + tid : nullptr;
+        bool ok = sub_two(cb, step_tag(r0), cs, yb, step_tag(k), ys, m, err, hb, step_tag(k));
+        double dot = 0.0;
+        if (k >= 0 && ok)
+            for (int i = 2 * tid; i < m; i += 2 * nthr) {                   // each thread re-reads only what it wrote
+                dot += ys[i] * vs[i];
+                if (i + 1 < m) dot += ys[i + 1] * vs[i + 1];
+            }
+        double bad = ok ? 0.0 : 1.0;
+        block_sum2(bad, dot, red, rs);
+        if (bad != 0.0) return;
+        SYTRD_TICK(2);                                    // waited for the column and y
+        // ---- d. w, column r0 after update k, its reflector — identical in every workgroup
+        const double al = -0.5 * tau * dot;
+        const double v0 = vs[0], w0 = (k >= 0 ? ys[0] : 0.0) + al * v0;
+        double part = 0.0;
+        for (int i = tid; i < m; i += nthr) {
+            const double wi = (k >= 0 ? ys[i] : 0.0) + al * vs[i];
+            ws[i] = wi;
+            const double x = cs[i] - (vs[i] * w0 + wi * v0);
+            cs[i] = x;
+            if (i >= 2) part += x * x;
+        }
+        const double xnorm2 = block_sum(part, red, rs);   // barrier: ws and cs (= x) are visible
+        const bool mine = g == r0 % G;
+        double *own = slab + (size_t)(r0 / G) * n + r0;   // my column r0 from its diagonal (owner only)
+        if (r0 == n - 1) {
+            if (mine && tid == 0) {
+                own[0] = cs[0];
+                D[r0] = cs[0];
+            }
+            break;
+        }
+        const double alpha = cs[1];
+        double tau_next = 0.0, beta = alpha, scale = 0.0;
+        if (xnorm2 != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau_next = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        for (int i = tid; i < m - 1; i += nthr) {         // v_{k+1}: index i <-> row r0 + 1 + i
+            const double v = (i == 0) ? 1.0 : cs[i + 1] * scale;
+            vnext[i] = v;
+            if (mine && i > 0) own[i + 1] = v;
+        }
+        if (mine && tid == 0) {
+            own[0] = cs[0];
+            own[1] = beta;
+            D[r0] = cs[0];
+            E[r0] = beta;
+            TAU[r0] = tau_next;
+        }
+        SYTRD_TICK(0);                                    // reflector (every workgroup)
+        // ---- e. fused: rank-2 update k of my columns j > r0 and y_{k+1}; column r0+1 is sent on by its owner
+        {
+            const int c0 = (r0 + 1 - g + G - 1) / G;
+            u64 *ynb = yg + (size_t)((k + 1) & 1) * ne;
+            u64 *cnb = cg + (size_t)((r0 + 1) & 1) * nv;
+            const unsigned ytag = step_tag(k + 1), ctag = step_tag(r0 + 1);
+            for (int cbase = c0; cbase < nc; cbase += cpp) {
+                const bool have = cbase + ce < nc;
+                const int j = g + (have ? cbase + ce : c0) * G;
+                double *col = slab + (size_t)(have ? cbase + ce : c0) * n + r0;
+                const double wj = ws[j - r0], vj = vs[j - r0];
+                const bool send = have && j == r0 + 1;
+                double s0 = 0.0, s1 = 0.0;
+                int i = seg;
+                for (; i + 32 < m; i += 64) {
+                    const double x0 = col[i] - (vs[i] * wj + ws[i] * vj);
+                    const double x1 = col[i + 32] - (vs[i + 32] * wj + ws[i + 32] * vj);
+                    if (have) { col[i] = x0; col[i + 32] = x1; }
+                    if (i >= 1) s0 += x0 * (i == 1 ? 1.0 : cs[i] * scale);
+                    s1 += x1 * cs[i + 32] * scale;                            // i + 32 >= 2 always
+                    if (send) {
+                        if (i >= 1) pub(cnb, i - 1, x0, ctag);
+                        pub(cnb, i + 31, x1, ctag);
+                    }
+                }
+                if (i < m) {
+                    const double x0 = col[i] - (vs[i] * wj + ws[i] * vj);
+                    if (have) col[i] = x0;
+                    if (i >= 1) {
+                        s0 += x0 * (i == 1 ? 1.0 : cs[i] * scale);
+                        if (send) pub(cnb, i - 1, x0, ctag);
+                    }
+                }
+                const double sy = half_sums(s0 + s1);
+                if (seg == 31 && have) pub(ynb, j - (r0 + 1), tau_next * sy, ytag);
+            }
+            if (tid == 0 && lastcol <= k + 1) pub(hg + (size_t)((k + 1) & 1) * G, g, 0.0, ytag);     // heartbeat (k+1)
+        }
+        __syncthreads();
+        double *t = vs;
+        vs = vnext;
+        vnext = t;
+        tau = tau_next;
+        SYTRD_TICK(3);                                    // fused update + y
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c)
+        for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
+    if (Qout)
+        for (int r = 0; r < nc; ++r)
+            for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * n + i] = qrow[(size_t)r * n + i];
+}
+
 }  // namespace jcdf
