@@ -3,7 +3,7 @@ SURVEY 8 row f1; reference: `eigen!(Hermitian(F'))`, SCF.jl:1083).
 
 rocSOLVER's syevd needs ~4000 tiny launches for the tridiagonalisation (9 of its 12 ms at
 N = 510).  Here the tridiagonalisation is ONE persistent kernel of libjcdf_hip.so
-(`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp) which also accumulates the orthogonal factor Q while
+(`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp: one hand-off per column up to N = 640, two above) which also accumulates the orthogonal factor Q while
 its reflectors travel between workgroups (A = Q T Q^T), so the back-transformation is one GEMM
 Q Z instead of LAPACK's ormtr (~30 launches, 1.1 ms).  The tridiagonal eigenproblem is solved by
 the library's own divide & conquer (`jcdf_stedc_device`, csrc/jcdf_dc.hpp: 1.0 ms at N = 510 where
