@@ -1032,11 +1032,20 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
     static const int onehop_env = getenv("JCDF_SYTRD_ONEHOP") ? atoi(getenv("JCDF_SYTRD_ONEHOP")) : -1;
     const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 640;
-    if (onehop && lds + (size_t)3 * n * 8 <= 160 * 1024) {
-        const size_t lds1 = lds + (size_t)3 * n * 8;
-        (void)hipFuncSetAttribute((const void *)k_sytrd_onehop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipLaunchKernelGGL(k_sytrd_onehop, dim3((unsigned)G), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
-                           hg, err, d_Q);
+    if (onehop && n <= 640) {
+        const int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
+        const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
+#define JCDF_ONEHOP(NR)                                                                                                     \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
+        hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
+                           d_TAU, vg, yg, hg, err, d_Q);                                                                    \
+    } while (0)
+        if (n <= 64) JCDF_ONEHOP(2);
+        else if (n <= 256) JCDF_ONEHOP(8);
+        else if (n <= 512) JCDF_ONEHOP(16);
+        else JCDF_ONEHOP(20);
+#undef JCDF_ONEHOP
         return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
     }
     (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

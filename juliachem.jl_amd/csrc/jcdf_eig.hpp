@@ -478,7 +478,8 @@ __device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *ds
 //      published at once; the owner of column k+2 broadcasts that column (now in the state step k+1 needs).
 // Buffers (parity of the item index), tags and the heartbeat rule as in k_sytrd_lower; here the heartbeat (k) is
 // fresh: a workgroup with no column > k publishes it where the others publish y_k.
-// LDS: ((Qout ? 2 : 1) * ncol_max * n + 5 n + 32) doubles.
+// LDS: (ncol_max * n + 5 n + 32) doubles; requires n <= 32 NR and at most 8 columns per workgroup.
+template <int NR>
 __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                       double *__restrict__ E, double *__restrict__ TAU,
                                                       u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
@@ -497,13 +498,15 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     double *ws = ys + n;                                  // w_k
     double *cs = ws + n;                                  // column k+1, then x = that column after update k
     double *red = cs + n;
-    double *qrow = red + 32;
     unsigned rs = 0;
     const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;
     const int ne = (n + 1) & ~1, nv = n + 2;              // buffer strides (even)
-    if (Qout)
-        for (int r = 0; r < nc; ++r)
-            for (int i = tid; i < n; i += nthr) qrow[(size_t)r * n + i] = (i == g + r * G) ? 1.0 : 0.0;
+    // my rows of Q live in REGISTERS: 32-lane group `ce` holds row g + ce*G (nc <= 8 = groups per workgroup, n <= 32 NR),
+    // lane `seg` its elements seg, seg+32, ... — the Q update then only reads v from LDS
+    const bool haveq = Qout && ce < nc;
+    double qreg[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) qreg[r] = (haveq && seg + 32 * r == g + ce * G) ? 1.0 : 0.0;
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) slab[(size_t)c * n + i] = A[(size_t)(g + c * G) * lda + i];
     for (int i = tid; i < n; i += nthr) vs[i] = ws[i] = 0.0;                // "update -1" is empty
@@ -517,28 +520,24 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     double tau = 0.0;
     for (int k = -1; k < n - 1; ++k) {
         const int r0 = k + 1, m = n - r0;                 // rows r0 .. n-1, relative index i <-> row r0 + i
-        // ---- a. while y_k travels: Q <- Q H_k on my rows of Q
+        // ---- a. while y_k travels: Q <- Q H_k on my row of Q (registers; v_k from LDS, index = column - r0)
         if (Qout && k >= 0) {
-            for (int rb = 0; rb < nc; rb += cpp) {
-                const bool have = rb + ce < nc;
-                double *q = qrow + (size_t)(have ? rb + ce : 0) * n + r0;
-                double s0 = 0.0, s1 = 0.0;
-                int i = seg;
-                for (; i + 32 < m; i += 64) {
-                    s0 += q[i] * vs[i];
-                    s1 += q[i + 32] * vs[i + 32];
-                }
-                if (i < m) s0 += q[i] * vs[i];
-                const double h = half_sums(s0 + s1);
-                const long long hb_ = __double_as_longlong(h);
-                const int lo31 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 31);
-                const int lo63 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 63);
-                const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
-                                              : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
-                const double sc = tau * tot;
-                if (have)
-                    for (int i2 = seg; i2 < m; i2 += 32) q[i2] -= sc * vs[i2];
+            double vr[NR], sq = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int c = seg + 32 * r;
+                vr[r] = (32 * r + 31 >= r0 && c >= r0 && c < n) ? vs[c - r0] : 0.0;
+                sq += qreg[r] * vr[r];
             }
+            const double h = half_sums(sq);
+            const long long hb_ = __double_as_longlong(h);
+            const int lo31 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 31);
+            const int lo63 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 63);
+            const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
+                                          : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
+            const double sc = tau * tot;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) qreg[r] -= sc * vr[r];
         }
         SYTRD_TICK(4);                                    // Q accumulation
         // ---- b + c. column r0 and y_k (+ heartbeat of the workgroups without a column > k), ONE round of polls
@@ -645,9 +644,11 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     __syncthreads();
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
-    if (Qout)
-        for (int r = 0; r < nc; ++r)
-            for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * n + i] = qrow[(size_t)r * n + i];
+    if (haveq) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (seg + 32 * r < n) Qout[(size_t)(g + ce * G) * n + seg + 32 * r] = qreg[r];
+    }
 }
 
 }  // namespace jcdf

@@ -25,10 +25,11 @@ int main(int argc, char **argv)
     const int lazy = argc > 4 ? atoi(argv[4]) : 0;
     const int nthr = argc > 5 ? atoi(argv[5]) : 256;
     const int onehop = argc > 6 ? atoi(argv[6]) : 0;             // 1: k_sytrd_onehop
-    const size_t lds = ((size_t)(withq ? 2 : 1) * ncol * n + (onehop ? 5 : 2) * n + 32) * 8;
+    const size_t lds = onehop ? ((size_t)ncol * n + 5 * n + 32) * 8 : ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
+    if (onehop && (ncol > 8 || n > 640)) { printf("onehop needs <= 8 columns per workgroup and n <= 640\n"); return 1; }
     double *dQ; hipMalloc(&dQ, A.size() * 8);
     hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void *)k_sytrd_onehop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)k_sytrd_onehop<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
         hipMemset(w, 0, wb);
@@ -37,7 +38,7 @@ int main(int argc, char **argv)
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         if (onehop)
-            hipLaunchKernelGGL(k_sytrd_onehop, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
+            hipLaunchKernelGGL(k_sytrd_onehop<20>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
                                (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
         else
         hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
