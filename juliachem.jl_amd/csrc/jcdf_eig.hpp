@@ -1,22 +1,24 @@
-// jcdf_eig.hpp — k_sytrd_lower: Householder tridiagonalisation of a symmetric fp64 matrix
-// in ONE persistent kernel launch (caller side of the hot path, SURVEY 8 row f1: the
+// jcdf_eig.hpp — k_sytrd_lower / k_sytrd_onehop: Householder tridiagonalisation of a symmetric fp64
+// matrix in ONE persistent kernel launch (caller side of the hot path, SURVEY 8 row f1: the
 // replicated eigensolve of `iteration`, /root/reference/src/rhf/energy/SCF.jl:1080-1083).
 //
 // Why: rocSOLVER's syevd spends ~9 of its 12 ms (N = 510) in ~4000 tiny latrd/symv/syr2
-// launches of the tridiagonalisation (profiles/r01_kernel_stats_bench.txt).  The algorithm
-// is LAPACK dsytd2 (unblocked, 'L'): N-2 dependent steps, each a symv and a rank-2 update of
-// the trailing matrix — only ~2.7e8 flops in total at N = 510, pure latency.  Here the matrix
-// lives in LDS, distributed column-cyclically over G workgroups (G <= #CUs, one per CU, all
-// co-resident), and the N-2 steps run inside one launch.
+// launches of the tridiagonalisation.  The algorithm is LAPACK dsytd2 (unblocked, 'L'): N-2
+// dependent steps, each a symv and a rank-2 update of the trailing matrix — only ~2.7e8 flops in
+// total at N = 510, pure latency.  Here the matrix lives in LDS, distributed column-cyclically over
+// G workgroups (G <= #CUs, one per CU, all co-resident), and the N-2 steps run inside one launch.
 //
 // Inter-workgroup hand-off: tagged 8-byte granules (see below) — no grid barrier, no fence; every
-// spin is bounded by a wall-clock timeout that raises an error word.  Per column two all-to-all
-// exchanges remain (the reflector v, then y = tau A v): ~7 us per column on MI355X, which is the
-// fabric's all-gather latency (MI355X_MICROARCH price list: 8 KB all-gather ~2.4-3 us), not
-// arithmetic.  A first version with two counter grid barriers per column measured the same 7.5 us.
+// spin is bounded by a wall-clock timeout that raises an error word.  One round of agent-scope polls
+// is a ~1.4 us round trip inside these kernels, so what counts is the number of DEPENDENT poll
+// rounds per column: k_sytrd_lower has two (reflector v + tau, then y = tau A v), k_sytrd_onehop one
+// (every workgroup forms the reflector itself from a column that was broadcast a step ahead).
+// History at N = 510, us per column: 7.5 (two counter grid barriers) -> 7.0 (granules) -> 5.9 (reductions
+// by DPP instead of ds_bpermute, Q accumulated in the kernel) -> 5.0 (tau travels with v) -> 4.6 (one hop).
 //
 // Output is LAPACK-compatible (dsytrd 'L'): D, E, TAU and the Householder vectors below the
-// sub-diagonal of A, so rocSOLVER's stedc + ormtr finish the eigendecomposition.
+// sub-diagonal of A (handed-off values rounded to 50 mantissa bits, see below), plus optionally the
+// accumulated orthogonal factor Q, so the eigenvectors are one GEMM Q Z after the tridiagonal solve.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -22,7 +22,7 @@ int main(int argc, char **argv)
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dD, n * 8); hipMalloc(&dE, n * 8); hipMalloc(&dT, n * 8); hipMalloc(&w, wb);
     const int ncol = (n + G - 1) / G;
     const bool withq = argc > 3 ? atoi(argv[3]) != 0 : true;
-    const int lazy = argc > 4 ? atoi(argv[4]) : 0;
+    (void)(argc > 4 ? atoi(argv[4]) : 0);                          // (argv[4] unused, kept for the positions of the others)
     const int nthr = argc > 5 ? atoi(argv[5]) : 256;
     const int onehop = argc > 6 ? atoi(argv[6]) : 0;             // 1: k_sytrd_onehop
     const size_t lds = onehop ? ((size_t)ncol * n + 5 * n + 32) * 8 : ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
