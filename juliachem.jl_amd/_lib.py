@@ -53,6 +53,7 @@ PROTOTYPES = {
     "jcdf_fock_build_begin": (C.c_int32, [_P, _P]),
     "jcdf_fock_build_finish": (C.c_int32, [_P, _P, C.POINTER(jcdf_timings)]),
     "jcdf_fock_build_device": (C.c_int32, [_P, _P, _P, _P]),
+    "jcdf_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "jcdf_synchronize": (C.c_int32, [_P, C.POINTER(jcdf_timings)]),
     "jcdf_get_V": (C.c_int32, [_P, _P]),
     "jcdf_get_W": (C.c_int32, [_P, _P]),

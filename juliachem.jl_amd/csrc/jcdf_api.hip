@@ -69,6 +69,9 @@ struct jcdf_handle {
     // timing
     std::vector<KernelRec> recs;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_h2d = nullptr, ev_d2h = nullptr;
+    hipStream_t side = nullptr;                      // the HBM-bound J pass runs beside the MFMA-bound K pass (overlap_jk)
+    bool overlap_jk = true;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timed_host_copy = false;
     bool pending = false;
 };
@@ -209,7 +212,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
         (void)hipEventRecord(r.e1, st);
     }
-    auto run_J = [&](size_t slot) {
+    auto run_J = [&](size_t slot, hipStream_t st) {
         KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st);
         hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)((h->N + J_ROWS - 1) / J_ROWS), (unsigned)h->SJ), dim3(256),
                            (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
@@ -235,7 +238,21 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     };
     // record slots stay fixed (2 = J, 3 = K) whatever the launch order
     static const bool k_first = [] { const char *e = getenv("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
-    if (k_first) { run_K(3); run_J(2); } else { run_J(2); run_K(3); }
+    static const int overlap_env = [] { const char *e = getenv("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
+    if (overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk) {
+        // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs
+        if (!h->side) {
+            (void)hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+            (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+        }
+        (void)hipEventRecord(h->ev_fork, st);
+        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        run_J(2, h->side);
+        run_K(3);
+        (void)hipEventRecord(h->ev_join, h->side);
+        (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    } else if (k_first) { run_K(3); run_J(2, st); } else { run_J(2, st); run_K(3); }
     k = 4;
     {
         KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st);
@@ -601,6 +618,9 @@ int32_t jcdf_destroy(jcdf_handle *h)
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
     if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return JCDF_OK;
@@ -891,6 +911,13 @@ int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_
     if (h->stage_rows) release_stage(h);
     h->timed_host_copy = false;
     return enqueue_fock(h, d_C_occ, d_F, stream ? (hipStream_t)stream : h->stream);
+}
+
+int32_t jcdf_set_overlap(jcdf_handle *h, int32_t overlap_jk)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    h->overlap_jk = overlap_jk != 0;
+    return JCDF_OK;
 }
 
 int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t)

@@ -436,6 +436,10 @@ class JCDFHandle:
         self._check(self._lib.jcdf_get_W(self._h, out.ctypes.data))
         return out
 
+    def set_overlap(self, overlap_jk: bool) -> None:
+        """J beside K on a side stream (default) or one after the other (stand-alone kernel timings)."""
+        self._check(self._lib.jcdf_set_overlap(self._h, 1 if overlap_jk else 0))
+
     def device_bytes(self) -> int:
         return int(self._lib.jcdf_device_bytes(self._h))
 
