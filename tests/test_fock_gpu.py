@@ -673,3 +673,63 @@ def test_rhf_run_two_ranks_on_one_gpu():
                                 for a in g["atoms"]]
     one = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], {"dele": 1e-8, "rmsd": 1e-8, "niter": 60, "df_use_adaptive": False})
     assert abs(got[0][1] - one["Energy"]) < 1e-9 and got[0][2] == one["Iterations"]
+
+
+def test_overlap_on_off_gives_identical_bits():
+    """J beside K on the side stream vs one after the other: they write different buffers, so F is bit-identical."""
+    N, Q, o = 130, 100, 17
+    s = synthetic.make(N, Q, o, seed=4)
+    B = orc.calculate_B(s.J2c, s.T)
+    h = _handle(N, Q, 0, Q, o)
+    h.set_B(np.asfortranarray(B.reshape(Q, N * N, order="F")))
+    h.set_core_hamiltonian(s.H)
+    F1, _ = h.fock_build(s.C[:, :o])
+    h.set_overlap(False)
+    F0, t0 = h.fock_build(s.C[:, :o])
+    h.set_overlap(True)
+    F2, _ = h.fock_build(s.C[:, :o])
+    assert np.array_equal(F0, F1) and np.array_equal(F0, F2)
+    assert _rel(F0, s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :o])) < RTOL
+    h.close()
+
+
+def test_reference_shaped_operator_with_the_library_integral_engine():
+    """df_rhf_fock_build (the reference's operator signature) fed by HostIntegralEngine instead of in-memory tensors:
+    real integrals, real Schwarz mask, packed layout, two aux shards on two handles — against the oracle's screened
+    algorithm with the same mask on the oracle's integrals."""
+    import json, os
+    from juliachem_jl_amd.integrals import HostIntegralEngine
+    from water_case import GOLDEN, FIXTURES
+    from oracle import integrals as gi
+    import pytest as _pt
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
+                                for a in g["atoms"]]
+    eng = HostIntegralEngine(atoms, g["basis"], g["aux_basis"], g["charges"])
+    S, T, V = eng.one_electron()
+    H = T + V
+    N, o = eng.prim.nbf, 10
+    bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes(eng.prim.shell_nbas, nels=2 * o),
+                                 jc.basis_from_shell_sizes(eng.aux.shell_nbas))
+    opts = jc.create_scf_options({"scf_type": "df", "contraction_mode": "GPU", "num_devices": 2, "df_use_adaptive": False})
+    import os as _os
+    _os.environ["JCDF_ALLOW_DEVICE_WRAP"] = "1"
+    try:
+        sd_gpu = jc.SCFData(jc.get_default_gpu_data_hip())
+        tm = jc.create_jctiming()
+        rng = np.random.default_rng(2)
+        C, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        F = jc.df_rhf_fock_build(sd_gpu, eng, None, bs, C, 1, opts, H, tm)
+    finally:
+        _os.environ.pop("JCDF_ALLOW_DEVICE_WRAP", None)
+    assert tm.non_timing_data["contraction_algorithm"] == "screened hip"
+    prim = gi.build_shells(atoms, g["basis"]); aux = gi.build_shells(atoms, g["aux_basis"])
+    J2 = gi.two_center(aux)
+    mask = eng.schwarz_mask(1e-5, float(np.max(np.diag(J2))))
+    assert not mask.all()
+    sd = orc.get_screening_metadata(mask)
+    Bp = orc.pack_three_center(orc.calculate_B(J2, gi.three_center(aux, prim)), sd)
+    ref = H + orc.df_rhf_fock_build_screened(Bp, C[:, :o], sd)
+    assert _rel(F, ref) < 1e-10
+    sd_gpu.gpu_data.close()
+    eng.close()
