@@ -200,6 +200,14 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
+ * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
+ * d_Bmat nd x nd ring buffer of error-vector dot products (row and column `head` are first overwritten with
+ * d_dots[nd]); n vectors in use, newest first slot_k = (head - k) mod nd; solve != 0: the bordered (n+1) system is
+ * solved and d_coef[slot] receives the extrapolation coefficients (0 for unused slots); solve == 0 or a singular /
+ * non-finite system (then d_flag[0] = 1, the reference's "Faulty DIIS" path): unit vector on the newest entry.  nd <= 15. */
+int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int32_t solve, double *d_Bmat,
+                         const double *d_dots, double *d_coef, int32_t *d_flag);
 /* Second stage of the same eigensolve: all eigenvalues and eigenvectors of the symmetric tridiagonal
  * matrix (d_D diagonal, d_E sub-diagonal, both device, length n and n-1) by divide & conquer
  * (LAPACK dstedc 'I' semantics; csrc/jcdf_dc.hpp).  On return (stream-ordered) d_D holds the eigenvalues

@@ -1094,6 +1094,16 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
     return n;
 }
 
+int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int32_t solve, double *d_Bmat, const double *d_dots,
+                         double *d_coef, int32_t *d_flag)
+{
+    if (nd < 1 || nd > 15 || head < 0 || head >= nd || n < 1 || n > nd || !d_Bmat || !d_dots || !d_coef || !d_flag)
+        return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_diis_solve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_Bmat, d_dots, (int)nd, (int)head, (int)n,
+                       (int)solve, d_coef, d_flag);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
 int64_t jcdf_stedc_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;

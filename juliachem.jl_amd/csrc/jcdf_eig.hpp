@@ -653,4 +653,80 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     }
 }
 
+// ---- k_diis_solve: the Pulay step of the SCF wrapper without a round trip to the host ----------------------------
+// (reference: DIIS in src/rhf/energy/EnergyHelpers.jl:234-258 — B matrix of error-vector dot products bordered by
+// -1, LAPACK.sysv!('U'), "Faulty DIIS" -> history cut to 2; called from SCF.jl:472-501.)
+// Bmat: nd x nd ring buffer of <e_i, e_j> (symmetric), dots[nd]: <e_slot, e_newest> for every slot (written into row
+// and column `head` first), n: vectors in use, newest-first order slot_k = (head - k) mod nd.  One workgroup; the
+// (n+1) x (n+1) system is solved by Gaussian elimination with partial pivoting in LDS (n <= 15).
+// coef[slot] = c (0 for unused slots).  A singular or non-finite system sets flag[0] = 1 and returns the unit vector
+// on the newest entry (no extrapolation this iteration), like the reference's exception path.
+__global__ __launch_bounds__(64) void k_diis_solve(double *__restrict__ Bmat, const double *__restrict__ dots, int nd, int head,
+                                                  int n, int solve, double *__restrict__ coef, int *__restrict__ flag)
+{
+    __shared__ double M[16][17];
+    __shared__ double rhs[16];
+    __shared__ int piv_row;
+    const int tid = threadIdx.x;
+    if (tid < nd) {
+        Bmat[(size_t)head * nd + tid] = dots[tid];
+        Bmat[(size_t)tid * nd + head] = dots[tid];
+    }
+    __syncthreads();
+    if (tid < nd) coef[tid] = (tid == head) ? 1.0 : 0.0;
+    if (!solve) return;
+    const int m = n + 1;
+    for (int idx = tid; idx < m * m; idx += 64) {
+        const int i = idx / m, j = idx % m;
+        double v;
+        if (i < n && j < n) v = Bmat[(size_t)((head - i + nd) % nd) * nd + (head - j + nd) % nd];
+        else v = (i == n && j == n) ? 0.0 : -1.0;
+        M[i][j] = v;
+    }
+    if (tid < m) rhs[tid] = (tid == n) ? -1.0 : 0.0;
+    __syncthreads();
+    bool bad = false;
+    for (int c = 0; c < m; ++c) {
+        if (tid == 0) {                                   // partial pivoting
+            int p = c;
+            double best = fabs(M[c][c]);
+            for (int r = c + 1; r < m; ++r)
+                if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+            piv_row = (best > 0.0 && isfinite(best)) ? p : -1;
+        }
+        __syncthreads();
+        const int p = piv_row;
+        if (p < 0) { bad = true; break; }
+        if (p != c) {
+            if (tid < m) { const double t = M[c][tid]; M[c][tid] = M[p][tid]; M[p][tid] = t; }
+            if (tid == 0) { const double t = rhs[c]; rhs[c] = rhs[p]; rhs[p] = t; }
+        }
+        __syncthreads();
+        const double d = M[c][c];
+        if (tid > c && tid < m) {                         // row `tid`
+            const double f = M[tid][c] / d;
+            for (int j = c; j < m; ++j) M[tid][j] -= f * M[c][j];
+            rhs[tid] -= f * rhs[c];
+        }
+        __syncthreads();
+    }
+    if (!bad && tid == 0) {                               // back substitution
+        for (int r = m - 1; r >= 0; --r) {
+            double x = rhs[r];
+            for (int j = r + 1; j < m; ++j) x -= M[r][j] * rhs[j];
+            rhs[r] = x / M[r][r];
+            if (!isfinite(rhs[r])) bad = true;
+        }
+        piv_row = bad ? -1 : 0;
+    }
+    __syncthreads();
+    if (bad || piv_row < 0) {
+        if (tid == 0) flag[0] = 1;
+        return;                                           // coef already = unit vector on the newest entry
+    }
+    if (tid < nd) coef[tid] = 0.0;
+    __syncthreads();
+    if (tid < n) coef[(head - tid + nd) % nd] = rhs[tid];
+}
+
 }  // namespace jcdf

@@ -96,6 +96,13 @@ class DeviceEigh:
         # column-major eigenvector matrix == transpose of the row-major view
         return self.D, self.Cm.T
 
+    def status(self) -> torch.Tensor:
+        """0-d float64 device tensor, non-zero iff the last call failed (hand-off timeout in the tridiagonalisation or
+        a vendor stedc failure) — for callers that fold it into a device-to-host copy they make anyway."""
+        if not self.ok:
+            return torch.zeros((), dtype=torch.float64, device=self.device)
+        return (self.work[1:2].view(torch.int32)[0].abs() + self.info[0].abs()).to(torch.float64)
+
     def check(self) -> bool:
         """True if the persistent kernel's grid barrier never timed out and stedc converged
         (reads two words from the device: call where the stream is synchronised anyway)."""

@@ -13,6 +13,7 @@ libjcdf_hip.so.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -163,7 +164,10 @@ class DeviceSCF:
         self.X = (U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T
         self.E_nuc = E_nuc
         self.ndiis = ndiis
-        self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + stedc + ormtr
+        self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM
+        from . import _lib
+        self._lib = _lib.load()
+        self.diis_on_host = bool(os.environ.get("JCDF_DIIS_HOST")) or self.ndiis > 15
         self.reset()
 
     def reset(self) -> None:
@@ -179,6 +183,9 @@ class DeviceSCF:
         self.F_hist = torch.zeros((nd, self.N * self.N), dtype=torch.float64, device=self.H.device)
         self.head, self.n_hist = -1, 0
         self.Bmat = np.zeros((nd, nd))
+        self.Bmat_d = torch.zeros((nd, nd), dtype=torch.float64, device=self.H.device)
+        self.coef_d = torch.zeros(nd, dtype=torch.float64, device=self.H.device)
+        self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.H.device)
         self.trail: List[Tuple[int, float, float, float]] = []
 
     def _diag(self) -> torch.Tensor:
@@ -211,7 +218,28 @@ class DeviceSCF:
                 self.seg = {}
         F = self.fb.build(self.Co_t).clone()                       # SCF.jl:463
         self._mark("fock")
-        if self.ndiis > 0:                                         # SCF.jl:472-501
+        if self.ndiis > 0 and not self.diis_on_host:               # SCF.jl:472-501, the Pulay system solved on the device
+            nd = self.ndiis
+            FDS = (F @ self.D) @ self.S
+            e = (FDS - FDS.T).reshape(-1)
+            self.head = (self.head + 1) % nd
+            self.n_hist = min(self.n_hist + 1, nd)
+            self.e_hist[self.head].copy_(e)
+            self.F_hist[self.head].copy_(F.reshape(-1))
+            dots = self.e_hist @ e                                 # <e_slot, e_new> for every slot: one GEMV, stays on the device
+            solve = self.iter > 1
+            if solve:
+                self.B_dim = min(self.B_dim + 1, nd)
+            rc = self._lib.jcdf_diis_device(ctypes.c_void_p(torch.cuda.current_stream(F.device).cuda_stream), nd, self.head,
+                                            self.B_dim if solve else 1, 1 if solve else 0,
+                                            ctypes.c_void_p(self.Bmat_d.data_ptr()), ctypes.c_void_p(dots.data_ptr()),
+                                            ctypes.c_void_p(self.coef_d.data_ptr()), ctypes.c_void_p(self.diis_flag.data_ptr()))
+            if rc != 0:
+                raise RuntimeError("jcdf_diis_device failed (status %d)" % rc)
+            if solve:
+                # sum_k c_k F_k as a GEMV on the transposed view; a faulty system leaves the unit vector on the newest F
+                F = torch.mv(self.F_hist.t(), self.coef_d).reshape(self.N, self.N)
+        elif self.ndiis > 0:                                       # host solve (JCDF_DIIS_HOST=1): one extra sync per iteration
             nd = self.ndiis
             FDS = (F @ self.D) @ self.S
             e = (FDS - FDS.T).reshape(-1)
@@ -251,8 +279,12 @@ class DeviceSCF:
         E_elec = self._diag()
         self._mark("diag")
         D_rms = torch.linalg.norm(self.D - D_old)
-        e_h, drms = torch.stack([E_elec, D_rms]).cpu().tolist()    # one 16-B D2H (host sync) per iteration
-        if not self.eigh.check():                                  # grid-barrier timeout / stedc failure: redo with the vendor solver
+        # ONE device-to-host copy (the only host sync of the iteration): energy, ||dD||, DIIS flag, eigensolver status
+        e_h, drms, faulty, eig_bad = torch.stack([E_elec, D_rms, self.diis_flag[0].to(torch.float64), self.eigh.status()]).cpu().tolist()
+        if faulty:                                                 # "Faulty DIIS!" SCF.jl:493-499 (seen one sync later)
+            self.B_dim = 2
+            self.diis_flag.zero_()
+        if eig_bad and not self.eigh.check():                      # hand-off timeout / stedc failure: redo with the vendor solver
             self.F = F
             E_elec = self._diag()
             D_rms = torch.linalg.norm(self.D - D_old)

@@ -733,3 +733,41 @@ def test_reference_shaped_operator_with_the_library_integral_engine():
     assert _rel(F, ref) < 1e-10
     sd_gpu.gpu_data.close()
     eng.close()
+
+
+def test_diis_device_matches_host_solve():
+    """jcdf_diis_device (Pulay system solved by one workgroup) against numpy on the bordered matrix of EnergyHelpers.jl:234-258,
+    ring-buffer order included; a singular system raises the flag and returns the unit vector on the newest entry."""
+    import ctypes as C
+    import torch
+    from juliachem_jl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    nd, head, n = 10, 3, 7
+    E = rng.standard_normal((nd, 40))
+    G = E @ E.T
+    f64 = dict(dtype=torch.float64, device="cuda")
+    Bm = torch.as_tensor(G.copy(), **f64)
+    Bm[head, :] = 0.0; Bm[:, head] = 0.0                                   # the kernel fills row/column `head` from dots
+    dots = torch.as_tensor(G[head].copy(), **f64)
+    coef = torch.full((nd,), 7.0, **f64)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.jcdf_diis_device(st, nd, head, n, 1, p(Bm), p(dots), p(coef), p(flag)) == 0
+    order = [(head - k) % nd for k in range(n)]
+    A = -np.ones((n + 1, n + 1)); A[:n, :n] = G[np.ix_(order, order)]; A[n, n] = 0.0
+    rhs = np.zeros(n + 1); rhs[n] = -1.0
+    c = np.linalg.solve(A, rhs)[:n]
+    ref = np.zeros(nd); ref[order] = c
+    assert np.allclose(Bm.cpu().numpy(), G) and int(flag.item()) == 0
+    assert np.abs(coef.cpu().numpy() - ref).max() < 1e-10 * np.abs(ref).max()
+    assert abs(coef.sum().item() - 1.0) < 1e-12                          # the constraint row
+    # solve == 0: history update only, unit vector
+    assert lib.jcdf_diis_device(st, nd, head, 1, 0, p(Bm), p(dots), p(coef), p(flag)) == 0
+    assert np.array_equal(coef.cpu().numpy(), np.eye(nd)[head]) and int(flag.item()) == 0
+    # singular: two identical error vectors
+    Z = torch.zeros((nd, nd), **f64)
+    assert lib.jcdf_diis_device(st, nd, 1, 3, 1, p(Z), p(torch.zeros(nd, **f64)), p(coef), p(flag)) == 0
+    assert int(flag.item()) == 1 and np.array_equal(coef.cpu().numpy(), np.eye(nd)[1])
+    assert lib.jcdf_diis_device(st, 16, 0, 1, 1, p(Z), p(dots), p(coef), p(flag)) == 1      # nd > 15 rejected
