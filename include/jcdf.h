@@ -217,6 +217,18 @@ int64_t jcdf_stedc_workspace_bytes(int64_t n);
 int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, double *d_Z, int64_t ldz,
                           void *d_work, int64_t work_bytes);
 
+/* Alternative to the eigensolve inside the SCF step (optional; SCF.jl:1072-1125 takes the density from eigen()):
+ * the spectral projector P onto the n_occ lowest eigenvectors of the symmetric matrix d_F (n x n, device,
+ * leading dimension ldf) by trace-correcting second-order spectral projection (csrc/jcdf_sp2.hpp) — matrix
+ * squarings on MFMA, no host round trip.  `iterations` squarings are enqueued; those after convergence return at
+ * once.  On return (stream-ordered) d_P (n x n, leading dimension ldp) holds the current iterate and d_info
+ * (8 doubles, device) = {squarings done, finished (1/0), tr P, last tr(X - X^2), Gershgorin lo, hi, -, -}:
+ * the caller accepts P when finished == 1 and |tr P - n_occ| is small, and otherwise calls again with more
+ * iterations or takes the eigensolver.  d_work: jcdf_sp2_workspace_bytes(n) bytes of device memory. */
+int64_t jcdf_sp2_workspace_bytes(int64_t n);
+int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_F, int64_t ldf, double *d_P, int64_t ldp,
+                        int32_t iterations, void *d_work, int64_t work_bytes, double *d_info);
+
 
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */

@@ -1,0 +1,318 @@
+// jcdf_sp2.hpp — the occupied-space projector of a symmetric matrix without an eigensolve.
+//
+// The SCF step needs only the density, i.e. the spectral projector P onto the n_occ lowest eigenvectors of
+// F' = X F X (SCF.jl:1072-1125 gets it from eigen() and C_occ C_occ^T).  Trace-correcting second-order
+// spectral projection (SP2; Niklasson, PRB 66, 155115) reaches P with symmetric matrix squarings only:
+//   X_0 = (hi I - F') / (hi - lo)                  lo/hi: Gershgorin bounds, spectrum mapped into [0, 1] and reversed
+//   X_{k+1} = X_k^2  or  2 X_k - X_k^2             whichever brings tr X closer to n_occ
+// X^2 pushes eigenvalues towards 0 (quadratically near 0, and doubles the distance to 1), 2X - X^2 the mirror
+// image; once tr(X - X^2) < 1e-8 one step of each kind in a row leaves every eigenvalue within O(1e-16) of 0 or 1.
+// About 30-60 squarings of an N x N matrix: MFMA work on all CUs instead of the N dependent hand-offs of a
+// tridiagonalisation.  Optional path (scf flag density_solver = "sp2"); the eigensolver stays the default.
+//
+// Device program: k_sp2_bounds, k_sp2_init once; per squaring k_sp2_square (lower block-triangle of X^2 on the TN
+// MFMA core — X is symmetric, so X^2 = X^T X is the k-major SYRK of the K kernel — split-K into slabs) and
+// k_sp2_update (slab sum in slice order, X_{k+1} tile and its mirror image into the other X buffer).
+// tr X^2 = ||X||_F^2 for symmetric X, so the traces that steer iteration k are left by update k-1 as partial sums
+// and every workgroup of update k takes the same decision from them.  (A one-launch form — last slice to arrive
+// reduces — was slower: the device-scope release/acquire it needs writes back and invalidates the XCD's L2,
+// 14 us for a two-workgroup launch.)  No host round trip: the host launches a fixed number of iterations; after
+// convergence the remaining launches return at once.  The decision state is double-buffered by iteration parity
+// (iteration k reads state[k & 1], workgroup 0 writes state[(k + 1) & 1]).  n <= 4096.
+#pragma once
+#include "jcdf_gemm.hpp"
+
+namespace jcdf {
+
+typedef GemmCfg<2, 2, 2, 2, 32> Sp2Cfg;          // 64 x 64 tile, 4 waves of 32 x 32, 32 k rows per LDS stage
+constexpr int SP2_T = 64;
+constexpr int SP2_PART = 8448;                   // partial-sum slots per parity: padded rows (first launch) or 4 per lower tile
+
+struct Sp2State {
+    int cur, phase, done, iters;                 // X buffer in use; 0 trace-guided, 1 = final 2X - X^2 pending; finished; squarings done
+    double lo, hi, idem, trace;                  // Gershgorin bounds; last tr(X - X^2); last tr(X)
+};
+
+__device__ __forceinline__ double sp2_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// per workgroup (4 waves, one row each per pass): min_i (d_i - r_i), max_i (d_i + r_i) over its rows
+__global__ __launch_bounds__(256) void k_sp2_bounds(const double *__restrict__ F, int64_t ldf, int n, double *__restrict__ part)
+{
+    __shared__ double slo[4], shi[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double lo = 1e300, hi = -1e300;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        double r = 0.0;
+        for (int j = lane; j < n; j += 64)
+            if (j != i) r += fabs(F[(int64_t)i * ldf + j]);
+        r = sp2_wave_sum(r);
+        const double d = F[(int64_t)i * ldf + i];
+        lo = fmin(lo, d - r);
+        hi = fmax(hi, d + r);
+    }
+    if (lane == 0) { slo[wave] = lo; shi[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+        part[2 * blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+    }
+}
+
+// X_0 into the padded buffer Xa (np rows, leading dimension ld, zero outside n x n); state[0]
+__global__ __launch_bounds__(256) void k_sp2_init(const double *__restrict__ F, int64_t ldf, int n, int np, const double *__restrict__ part,
+                                                  int npart, double *__restrict__ Xa, int64_t ld, Sp2State *state,
+                                                  double *__restrict__ partials)
+{
+    __shared__ double slo[256], shi[256];
+    double lo = 1e300, hi = -1e300;
+    for (int p = threadIdx.x; p < npart; p += 256) {
+        lo = fmin(lo, part[2 * p]);
+        hi = fmax(hi, part[2 * p + 1]);
+    }
+    slo[threadIdx.x] = lo;
+    shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + s]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    lo = slo[0];
+    hi = shi[0];
+    const double w = (hi - lo > 1e-300) ? 1.0 / (hi - lo) : 1.0;
+    // one row per workgroup (gridDim.x == np); partials[row] = {X_0[row][row], sum_j X_0[row][j]^2}
+    {
+        const int i = blockIdx.x;
+        double fro = 0.0, tr = 0.0;
+        for (int j = threadIdx.x; j < ld; j += 256) {
+            double v = 0.0;
+            if (i < n && j < n) v = ((i == j ? hi : 0.0) - F[(int64_t)i * ldf + j]) * w;
+            Xa[(int64_t)i * ld + j] = v;
+            fro += v * v;
+            if (i == j) tr = v;
+        }
+        __syncthreads();
+        slo[threadIdx.x] = tr;
+        shi[threadIdx.x] = fro;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                slo[threadIdx.x] += slo[threadIdx.x + s];
+                shi[threadIdx.x] += shi[threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            partials[2 * i] = slo[0];
+            partials[2 * i + 1] = shi[0];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Sp2State s;
+        s.cur = 0; s.phase = 0; s.done = 0; s.iters = 0;
+        s.lo = lo; s.hi = hi; s.idem = 0.0; s.trace = 0.0;
+        state[0] = s;
+    }
+}
+
+// Decision of iteration k from the partial sums {tr X_k, ||X_k||_F^2 = tr X_k^2} the previous launch left
+// (every workgroup sums them in the same order and so takes the same decision).
+struct Sp2Decision { int branch, phase_next, done_next; double tx, idem; };   // branch 0: X^2, 1: 2X - X^2
+
+__device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx, double t2, int n_occ, double (*red)[256])
+{
+    red[0][threadIdx.x] = tx;
+    red[1][threadIdx.x] = t2;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    tx = red[0][0];
+    t2 = red[1][0];
+    __syncthreads();
+    Sp2Decision d;
+    d.tx = tx;
+    d.idem = tx - t2;
+    d.phase_next = st.phase;
+    d.done_next = 0;
+    if (st.phase == 1) {
+        d.branch = 1;
+        d.done_next = 1;
+    } else if (fabs(d.idem) < 1e-8 && st.iters > 0) {
+        d.branch = 0;
+        d.phase_next = 1;
+    } else {
+        d.branch = (fabs(t2 - n_occ) < fabs(2.0 * tx - t2 - n_occ)) ? 0 : 1;
+    }
+    return d;
+}
+
+__device__ __forceinline__ void sp2_tile(int tile, int &ti, int &tj)
+{
+    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    tj = tile - ti * (ti + 1) / 2;
+}
+
+// slab[s][tile (ti >= tj)] = sum over the k chunks of slice s of X[k][ti-block]^T X[k][tj-block].
+// The X buffer in use is the parity of k (every squaring flips it); the state is not read here, so nothing stands
+// between the launch and the first operand loads — after convergence the remaining launches square for nothing.
+__global__ __launch_bounds__(Sp2Cfg::NT) void k_sp2_square(const double *__restrict__ Xa, const double *__restrict__ Xb, int64_t ld,
+                                                            int nsplit, int chunks, double *__restrict__ slabs, int64_t slab_stride, int k)
+{
+    extern __shared__ __align__(16) double smem[];
+    const double *X = (k & 1) ? Xb : Xa;
+    const int tile = blockIdx.x / nsplit, s = blockIdx.x % nsplit;
+    int ti, tj;
+    sp2_tile(tile, ti, tj);
+    const int c0 = (int)((int64_t)chunks * s / nsplit), c1 = (int)((int64_t)chunks * (s + 1) / nsplit);
+    double4_t acc[Sp2Cfg::WM][Sp2Cfg::WN];
+#pragma unroll
+    for (int m = 0; m < Sp2Cfg::WM; ++m)
+#pragma unroll
+        for (int nn = 0; nn < Sp2Cfg::WN; ++nn) acc[m][nn] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (c1 > c0)
+        gemm_tn_core<Sp2Cfg, false, 0, 2>(X + (int64_t)c0 * Sp2Cfg::KC * ld + ti * SP2_T, ld,
+                                          X + (int64_t)c0 * Sp2Cfg::KC * ld + tj * SP2_T, ld, c1 - c0, acc, smem);
+    double *out = slabs + (int64_t)s * slab_stride + (int64_t)(ti * SP2_T) * ld + tj * SP2_T;
+#pragma unroll
+    for (int m = 0; m < Sp2Cfg::WM; ++m)
+#pragma unroll
+        for (int nn = 0; nn < Sp2Cfg::WN; ++nn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                out[(int64_t)tile_row<Sp2Cfg>(m, j) * ld + tile_col<Sp2Cfg>(nn)] = acc[m][nn][j];
+}
+
+// One workgroup per quarter (16 rows) of a lower tile: decision from the previous launch's partial sums, slab sum in
+// slice order, X_{k+1} rows + their mirror image into the other X buffer, partial sums of X_{k+1} for the next launch.
+// Every global load (state, partial sums, X, slabs) is issued before the first use of any of them: one round trip.
+template <int NS>
+__global__ __launch_bounds__(256) void k_sp2_update(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
+                                                    double *Xb_w, int64_t ld, int n_occ, const double *__restrict__ slabs,
+                                                    int64_t slab_stride, double *partials, int npart0, int ntri, Sp2State *state, int k)
+{
+    __shared__ double red[2][256];
+    __shared__ double T[SP2_T][17];
+    const double *X = (k & 1) ? Xb : Xa;
+    double *Xn = (k & 1) ? Xa_w : Xb_w;
+    const double *pin = partials + (int64_t)(k & 1) * 2 * SP2_PART;
+    double *pout = partials + (int64_t)((k + 1) & 1) * 2 * SP2_PART;
+    const int tile = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    int ti, tj;
+    sp2_tile(tile, ti, tj);
+    const int c2 = (threadIdx.x & 31) * 2, r0 = threadIdx.x >> 5;
+    // loads first
+    const Sp2State st = state[k & 1];
+    double2_t x[2], q[2][NS];
+    int64_t off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        off[i] = (int64_t)(ti * SP2_T + 16 * quarter + r0 + 8 * i) * ld + tj * SP2_T + c2;
+        x[i] = *reinterpret_cast<const double2_t *>(X + off[i]);
+#pragma unroll
+        for (int h = 0; h < NS; ++h) q[i][h] = *reinterpret_cast<const double2_t *>(slabs + (int64_t)h * slab_stride + off[i]);
+    }
+    const int np_in = (k == 0) ? npart0 : 4 * ntri;
+    double tx = 0.0, t2 = 0.0;
+    for (int p = threadIdx.x; p < np_in; p += 256) {
+        const double2_t v = *reinterpret_cast<const double2_t *>(pin + 2 * p);
+        tx += v[0];
+        t2 += v[1];
+    }
+    if (st.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) state[(k + 1) & 1] = st;
+        return;
+    }
+    const Sp2Decision d = sp2_decide(st, tx, t2, n_occ, red);
+    double ptr = 0.0, pfro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = r0 + 8 * i, r = 16 * quarter + rl;               // row inside the quarter / inside the tile
+        double2_t sum = q[i][0];
+#pragma unroll
+        for (int h = 1; h < NS; ++h) sum += q[i][h];
+        const double2_t v = d.branch ? (2.0 * x[i] - sum) : sum;
+        *reinterpret_cast<double2_t *>(Xn + off[i]) = v;
+        T[c2][rl] = v[0];
+        T[c2 + 1][rl] = v[1];
+        pfro += v[0] * v[0] + v[1] * v[1];
+        if (ti == tj) ptr += (r == c2 ? v[0] : 0.0) + (r == c2 + 1 ? v[1] : 0.0);
+    }
+    if (ti != tj) {
+        __syncthreads();
+        const int c = threadIdx.x >> 2, rr = (threadIdx.x & 3) * 4;       // mirrored: row c of tile (tj, ti), 16 columns
+        double *dst = Xn + (int64_t)(tj * SP2_T + c) * ld + ti * SP2_T + 16 * quarter + rr;
+        *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
+        *reinterpret_cast<double2_t *>(dst + 2) = double2_t{T[c][rr + 2], T[c][rr + 3]};
+        pfro *= 2.0;
+    }
+    __syncthreads();
+    red[0][threadIdx.x] = ptr;
+    red[1][threadIdx.x] = pfro;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *reinterpret_cast<double2_t *>(pout + 2 * blockIdx.x) = double2_t{red[0][0], red[1][0]};
+        if (blockIdx.x == 0) {
+            Sp2State nx = st;
+            nx.cur = (k + 1) & 1;
+            nx.phase = d.phase_next;
+            nx.done = d.done_next;
+            nx.iters = st.iters + 1;
+            nx.idem = d.idem;
+            nx.trace = d.tx;
+            state[(k + 1) & 1] = nx;
+        }
+    }
+}
+
+// P (n x n, leading dimension ldp) <- current X; info = {squarings, finished, tr P, last tr(X - X^2)}
+__global__ __launch_bounds__(256) void k_sp2_finish(const double *__restrict__ Xa, const double *__restrict__ Xb, int64_t ld, int n,
+                                                    double *__restrict__ P, int64_t ldp, const Sp2State *__restrict__ state, int k,
+                                                    double *__restrict__ info)
+{
+    __shared__ double red[256];
+    const Sp2State st = state[k & 1];
+    const double *X = st.cur ? Xb : Xa;
+    for (int i = blockIdx.x; i < n; i += gridDim.x)
+        for (int j = threadIdx.x; j < n; j += 256) P[(int64_t)i * ldp + j] = X[(int64_t)i * ld + j];
+    if (blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) t += X[(int64_t)i * ld + i];
+        red[threadIdx.x] = t;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            info[0] = (double)st.iters;
+            info[1] = (double)st.done;
+            info[2] = red[0];
+            info[3] = st.idem;
+            info[4] = st.lo;
+            info[5] = st.hi;
+        }
+    }
+}
+
+}  // namespace jcdf

@@ -114,3 +114,41 @@ class DeviceEigh:
             self.ok = False
             self.reason = "sytrd barrier timeout" if err else "stedc info=%d" % int(self.info.item())
         return not bad
+
+
+class DeviceSP2:
+    """The projector onto the n_occ lowest eigenvectors of a symmetric matrix without an eigensolve
+    (`jcdf_sp2_device`, csrc/jcdf_sp2.hpp: trace-correcting spectral projection, matrix squarings on MFMA).
+    Optional replacement of the per-iteration eigensolve in DeviceSCF (scf flag density_solver = "sp2"): the SCF
+    energy, density and DIIS error depend on the occupied SPACE only (SCF.jl:1072-1125 forms D = 2 C_o C_o^T).
+    No host round trip: `iterations` squarings are enqueued (adapted from the count the previous call needed),
+    `info` stays on the device for the caller's one copy per SCF iteration."""
+
+    def __init__(self, n: int, n_occ: int, device: torch.device):
+        self.n, self.n_occ, self.device = n, n_occ, device
+        self.lib = _lib.load()
+        f64 = dict(dtype=torch.float64, device=device)
+        self.wb = int(self.lib.jcdf_sp2_workspace_bytes(n))
+        self.work = torch.zeros(self.wb // 8 + 8, **f64)
+        self.P = torch.empty((n, n), **f64)
+        self.info = torch.zeros(8, **f64)
+        self.iterations = int(os.environ.get("JCDF_SP2_ITERATIONS", "72"))
+        self.fixed = "JCDF_SP2_ITERATIONS" in os.environ
+        self.calls = 0
+
+    def __call__(self, Fp: torch.Tensor, iterations: Optional[int] = None) -> torch.Tensor:
+        self.calls += 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        Fp = Fp.contiguous()
+        rc = self.lib.jcdf_sp2_device(C.c_void_p(st), self.n, self.n_occ, C.c_void_p(Fp.data_ptr()), self.n,
+                                      C.c_void_p(self.P.data_ptr()), self.n, int(iterations or self.iterations),
+                                      C.c_void_p(self.work.data_ptr()), self.wb, C.c_void_p(self.info.data_ptr()))
+        if rc != 0:
+            raise RuntimeError("jcdf_sp2_device failed (status %d)" % rc)
+        return self.P
+
+    def adapt(self, used: float, finished: bool) -> None:
+        """after the caller has read info: enqueue (needed + 4) squarings next time, at least 16, more after a miss"""
+        if self.fixed:
+            return
+        self.iterations = min(400, max(16, int(used) + 4)) if finished else min(400, 2 * self.iterations)

@@ -153,7 +153,12 @@ class DeviceSCF:
     """SCF iteration with all matrices on the device (hcore guess, DIIS, damping;
     SURVEY Appendix D).  Matrices are symmetric, so row/column-major coincide."""
 
-    def __init__(self, fb: DeviceFockBuilder, H: np.ndarray, S: np.ndarray, E_nuc: float, ndiis: int = 10):
+    def __init__(self, fb: DeviceFockBuilder, H: np.ndarray, S: np.ndarray, E_nuc: float, ndiis: int = 10,
+                 density_solver: Optional[str] = None):
+        """density_solver: "eigh" (default; the reference's eigen() per iteration) or "sp2": the occupied-space
+        projector by spectral projection (eigh.DeviceSP2) and an orthonormal basis of it from the previous
+        iteration's occupied orbitals — same density, energy and DIIS error; orbital energies and canonical
+        orbitals only after canonical_orbitals().  $JCDF_DENSITY_SOLVER overrides."""
         self.fb = fb
         dev = fb.device
         self.N, self.n_occ = fb.N, fb.n_occ
@@ -165,6 +170,19 @@ class DeviceSCF:
         self.E_nuc = E_nuc
         self.ndiis = ndiis
         self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM
+        self.density_solver = (os.environ.get("JCDF_DENSITY_SOLVER") or density_solver or "eigh").lower()
+        if self.density_solver not in ("eigh", "sp2"):
+            raise ValueError("density_solver %r: \"eigh\" or \"sp2\"" % self.density_solver)
+        self.sp2 = None
+        if self.density_solver == "sp2" and 0 < self.n_occ < self.N and self.N >= 2:
+            from .eigh import DeviceSP2
+            self.sp2 = DeviceSP2(self.N, self.n_occ, dev)
+        self.sp2_status = torch.zeros(4, dtype=torch.float64, device=dev)     # {finished, tr P, min pivot of the basis Cholesky, squarings}
+        self.sp2_steps = self.sp2_fallbacks = 0
+        self.sp2_two_pass = True
+        self.sp2_reasons = {}
+        self.sp2_skip = True                     # first step, and while the density still changes wholesale: eigensolver
+        self.canonical = True                    # self.C / self.eps are the eigenvectors / eigenvalues of self.F
         from . import _lib
         self._lib = _lib.load()
         self.diis_on_host = bool(os.environ.get("JCDF_DIIS_HOST")) or self.ndiis > 15
@@ -188,14 +206,43 @@ class DeviceSCF:
         self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.H.device)
         self.trail: List[Tuple[int, float, float, float]] = []
 
-    def _diag(self) -> torch.Tensor:
+    def _diag(self, use_sp2: bool = False) -> torch.Tensor:
         """SCF.jl:1072-1125: F' = X F X, eigh, C = X U, D = 2 C_o C_o^T, E_elec."""
         Fp = self.X @ self.F @ self.X
-        self.eps, U = self.eigh(Fp)
-        self.C = self.X @ U
-        self.Co_t = self.C[:, :self.n_occ].T.contiguous()          # (o, N) row-major == (N, o) column-major
+        if use_sp2:
+            # occupied-space projector P of F' by spectral projection; orthonormal basis of its range from the previous
+            # occupied orbitals Cp (orthogonal basis): Y = P Cp, Y^T Y = L L^T, Cp_new^T = L^-1 Y^T, so that
+            # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (checked through the pivots)
+            P = self.sp2(Fp)
+            Yt = self.Cp_t @ P                                      # (o, N) = (P Cp)^T
+            L, _ = torch.linalg.cholesky_ex(Yt @ Yt.T)
+            pivot = torch.diagonal(L).min()
+            Cp_t = torch.linalg.solve_triangular(L, Yt, upper=False)
+            if self.sp2_two_pass:
+                # the new occupied space has turned far from the old one (small pivots, early iterations): Y^T Y is
+                # ill-conditioned and one Cholesky pass leaves Cp orthonormal only to cond * eps — second pass (CholQR2)
+                L2, _ = torch.linalg.cholesky_ex(Cp_t @ Cp_t.T)
+                Cp_t = torch.linalg.solve_triangular(L2, Cp_t, upper=False)
+            self.Cp_t = Cp_t
+            self.Co_t = self.Cp_t @ self.X                          # (o, N): rows = occupied orbitals in the AO basis
+            self.sp2_status = torch.stack([self.sp2.info[1], self.sp2.info[2], pivot, self.sp2.info[0]])
+            self.canonical = False
+        else:
+            self.eps, U = self.eigh(Fp)
+            self.C = self.X @ U
+            self.Cp_t = U[:, :self.n_occ].T.contiguous()            # occupied orbitals in the orthogonal basis, (o, N)
+            self.Co_t = self.C[:, :self.n_occ].T.contiguous()       # (o, N) row-major == (N, o) column-major
+            self.canonical = True
         self.D = 2.0 * (self.Co_t.T @ self.Co_t)
         return 0.5 * (torch.sum(self.D * self.F) + torch.sum(self.D * self.H))
+
+    def canonical_orbitals(self) -> None:
+        """Eigenvectors / eigenvalues of the current Fock matrix into self.C / self.eps (what the reference has after
+        every iteration; with density_solver = "sp2" only on request)."""
+        if not self.canonical:
+            self.eps, U = self.eigh(self.X @ self.F @ self.X)
+            self.C = self.X @ U
+            self.canonical = True
 
     profile = False
 
@@ -276,19 +323,36 @@ class DeviceSCF:
         self.F_old = F.clone()
         D_old = self.D
         self._mark("damp")
-        E_elec = self._diag()
+        use_sp2 = self.sp2 is not None and not self.sp2_skip
+        E_elec = self._diag(use_sp2)
         self._mark("diag")
         D_rms = torch.linalg.norm(self.D - D_old)
         # ONE device-to-host copy (the only host sync of the iteration): energy, ||dD||, DIIS flag, eigensolver status
-        e_h, drms, faulty, eig_bad = torch.stack([E_elec, D_rms, self.diis_flag[0].to(torch.float64), self.eigh.status()]).cpu().tolist()
+        host = torch.cat([torch.stack([E_elec, D_rms, self.diis_flag[0].to(torch.float64), self.eigh.status()]),
+                          self.sp2_status]).cpu().tolist()
+        e_h, drms, faulty, eig_bad = host[:4]
         if faulty:                                                 # "Faulty DIIS!" SCF.jl:493-499 (seen one sync later)
             self.B_dim = 2
             self.diis_flag.zero_()
+        if use_sp2:
+            finished, trace, pivot, used = host[4:8]
+            good = finished == 1.0 and abs(trace - self.n_occ) < 1e-6 and pivot > 1e-2 and math.isfinite(e_h)
+            self.sp2_two_pass = not (pivot > 0.9)                  # next iteration: the spaces turn smoothly
+            self.sp2.adapt(used, finished == 1.0)
+            self.sp2_steps += 1
+            if not good:                                           # not converged in the squarings enqueued / basis lost: eigensolve
+                self.sp2_fallbacks += 1
+                why = "unfinished" if finished != 1.0 else "trace" if abs(trace - self.n_occ) >= 1e-6 else "pivot" if not pivot > 1e-2 else "nan"
+                self.sp2_reasons[why] = self.sp2_reasons.get(why, 0) + 1
+                E_elec = self._diag(False)
+                D_rms = torch.linalg.norm(self.D - D_old)
+                e_h, drms, eig_bad = torch.stack([E_elec, D_rms, self.eigh.status()]).cpu().tolist()
         if eig_bad and not self.eigh.check():                      # hand-off timeout / stedc failure: redo with the vendor solver
             self.F = F
             E_elec = self._diag()
             D_rms = torch.linalg.norm(self.D - D_old)
             e_h, drms = torch.stack([E_elec, D_rms]).cpu().tolist()
+        self.sp2_skip = not (drms < 15.0)       # occupied space still turning by ~90 degrees somewhere: no basis to project
         E = e_h + self.E_nuc
         dE = E - self.E_old
         self.trail.append((self.iter, E, dE, drms))

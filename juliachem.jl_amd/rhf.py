@@ -110,7 +110,7 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
         fb.exchange_three_center(torch.as_tensor(np.ravel(T_own, order="K"), device=fb.device))
         del T_own
     jc_timing.timings[JCTC.three_eri_time] = t_eri
-    scf = DeviceSCF(fb, H, S, E_nuc)
+    scf = DeviceSCF(fb, H, S, E_nuc, density_solver=flags.get("density_solver"))
     converged = False
     E = 0.0
     it = 0
@@ -121,6 +121,7 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
         if abs(dE) <= opts.df_energy_convergence and drms <= opts.df_density_convergence:
             converged = True
             break
+    scf.canonical_orbitals()                                               # no-op with the default eigensolver
     eps = scf.eps.cpu().numpy()
     C = scf.C.cpu().numpy()
     Cocc = C[:, :n_occ]
@@ -133,7 +134,9 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     out = {"Fock": sym(scf.F.cpu().numpy()), "Density": sym(scf.D.cpu().numpy()), "Energy-Weighted Density": sym(W),
            "MO Coeff": np.ascontiguousarray(C[u, :]), "Overlap": sym(S), "Energy": E, "Converged?": converged, "Timings": jc_timing,
            "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail),
-           "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes()}
+           "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes(),
+           "Density Solver": {"name": scf.density_solver, "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks,
+                              "sp2_fallback_reasons": dict(scf.sp2_reasons)}}
     fb.close()
     eng.close()
     return out

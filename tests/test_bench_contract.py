@@ -28,6 +28,9 @@ def test_bench_prints_the_contract_line():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0.3 < rf["frac"] < 1.0 and d["value"] > 50.0
+    # the optional spectral-projection density solver is reported beside, on the same problem, with the same energy
+    assert d["density_solver"]["name"] == "eigh"
+    assert d["alt"]["density_solver"] == "sp2" and d["alt"]["value"] > 50.0 and abs(d["alt"]["energy_minus_eigh"]) < 1e-6
 
 
 def test_bench_cpu_baseline_object_shape():

@@ -771,3 +771,79 @@ def test_diis_device_matches_host_solve():
     assert lib.jcdf_diis_device(st, nd, 1, 3, 1, p(Z), p(torch.zeros(nd, **f64)), p(coef), p(flag)) == 0
     assert int(flag.item()) == 1 and np.array_equal(coef.cpu().numpy(), np.eye(nd)[1])
     assert lib.jcdf_diis_device(st, 16, 0, 1, 1, p(Z), p(dots), p(coef), p(flag)) == 1      # nd > 15 rejected
+
+
+# ---- optional density solver: spectral projection instead of the eigensolve (jcdf_sp2_device, csrc/jcdf_sp2.hpp) ------
+def _spectrum_matrix(n, o, gap, seed, dev):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Qm, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=g))
+    ev = torch.cat([torch.linspace(-20.0, -0.5, o, dtype=torch.float64), torch.linspace(-0.5 + gap, 6.0, n - o, dtype=torch.float64)])
+    F = (Qm * ev) @ Qm.T
+    return (0.5 * (F + F.T)).to(dev), (Qm[:, :o] @ Qm[:, :o].T).to(dev)
+
+
+@pytest.mark.parametrize("n,o,gap", [(2, 1, 1.0), (7, 3, 0.5), (64, 10, 0.5), (65, 64, 0.3), (100, 37, 0.1), (130, 5, 0.3),
+                                     (510, 81, 0.5), (510, 81, 0.01), (700, 350, 0.2), (1250, 250, 0.5)])
+def test_sp2_projector_equals_eigensolver_projector(n, o, gap):
+    """P from matrix squarings == sum of the o lowest eigenvectors' outer products (to roundoff), exactly symmetric,
+    integer trace; sizes off the 64-tile grid, one to four k slices, tiny gap."""
+    import torch
+    from juliachem_jl_amd.eigh import DeviceSP2
+    dev = torch.device("cuda", 0)
+    F, Pref = _spectrum_matrix(n, o, gap, 5 + n, dev)
+    sp = DeviceSP2(n, o, dev)
+    P = sp(F, 150).clone()
+    its, finished, trace, idem = sp.info.cpu().tolist()[:4]
+    assert finished == 1.0 and 2 <= its < 150
+    assert abs(trace - o) < 1e-10 and abs(idem) < 1e-8
+    assert (P - P.T).abs().max().item() == 0.0
+    assert (P - Pref).abs().max().item() < 1e-11
+    assert (P @ P - P).abs().max().item() < 1e-12
+    # deterministic: a second run gives the same bits
+    assert torch.equal(sp(F, 150), P)
+
+
+def test_sp2_reports_unfinished_and_rejects_bad_arguments():
+    import ctypes
+    import torch
+    from juliachem_jl_amd.eigh import DeviceSP2
+    dev = torch.device("cuda", 0)
+    F, _ = _spectrum_matrix(200, 40, 0.05, 3, dev)
+    sp = DeviceSP2(200, 40, dev)
+    sp(F, 5)
+    its, finished = sp.info.cpu().tolist()[:2]
+    assert its == 5.0 and finished == 0.0
+    sp.adapt(its, False)
+    assert sp.iterations == 144                      # doubled after a miss
+    lib = sp.lib
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.jcdf_sp2_device(st, 200, 0, p(F), 200, p(sp.P), 200, 10, p(sp.work), sp.wb, p(sp.info)) == 1  # JCDF_ERR_INVALID
+    assert lib.jcdf_sp2_device(st, 200, 200, p(F), 200, p(sp.P), 200, 10, p(sp.work), sp.wb, p(sp.info)) == 1  # JCDF_ERR_INVALID
+    assert lib.jcdf_sp2_device(st, 200, 40, p(F), 100, p(sp.P), 200, 10, p(sp.work), sp.wb, p(sp.info)) == 1  # JCDF_ERR_INVALID
+    assert lib.jcdf_sp2_device(st, 200, 40, p(F), 200, p(sp.P), 200, 10, p(sp.work), sp.wb - 1, p(sp.info)) == 1  # JCDF_ERR_INVALID
+    assert lib.jcdf_sp2_workspace_bytes(0) == 0
+
+
+@pytest.mark.parametrize("case,tol", [("ccpvdz", 1e-9), ("631g2dfp", 1e-7)])
+def test_scf_with_sp2_follows_the_eigensolver_trail(case, tol):
+    """density_solver = "sp2": same energies along the whole SCF trail as with the eigensolver (the density depends on
+    the occupied space only), the reference's final energy, canonical orbitals and orbital energies at the end."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES[case])))
+    f = {"dele": 1e-6, "rmsd": 1e-6, "niter": 50 if case == "ccpvdz" else 20}
+    a = rhf.run(g["atoms"], g["charges"], g["basis"], g["aux_basis"], f)
+    b = rhf.run(g["atoms"], g["charges"], g["basis"], g["aux_basis"], dict(f, density_solver="sp2"))
+    assert a["Density Solver"]["name"] == "eigh" and b["Density Solver"]["name"] == "sp2"
+    assert b["Density Solver"]["sp2_steps"] - b["Density Solver"]["sp2_fallbacks"] >= 5        # it really ran
+    assert b["Converged?"] and b["Iterations"] == a["Iterations"]
+    assert abs(b["Energy"] - g["final_energy"]) < tol
+    assert max(abs(x[1] - y[1]) for x, y in zip(a["Trail"], b["Trail"])) < 1e-9
+    assert np.abs(a["Density"] - b["Density"]).max() < 1e-9
+    assert np.abs(a["Orbital Energies"] - b["Orbital Energies"]).max() < 1e-9
+    n = b["Overlap"].shape[0]
+    assert np.allclose(b["MO Coeff"].T @ b["Overlap"] @ b["MO Coeff"], np.eye(n), atol=1e-9)
+    assert np.allclose(b["MO Coeff"].T @ b["Fock"] @ b["MO Coeff"], np.diag(b["Orbital Energies"]), atol=1e-8)
