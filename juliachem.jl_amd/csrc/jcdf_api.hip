@@ -1108,29 +1108,23 @@ int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int3
 // ---- SP2 density solver (jcdf_sp2.hpp) -----------------------------------------------------------
 namespace {
 struct Sp2Work {
-    double *Xa, *Xb, *slabs, *part, *partials;
+    double *Xa, *Xb, *part, *partials;
     Sp2State *state;
-    int64_t np, ld, slab_stride, bytes;
-    int nsplit, chunks, nt, ntri;
+    int64_t np, ld, bytes;
+    int chunks, ntri;
 };
 Sp2Work sp2_carve(char *base, int64_t n)
 {
     Sp2Work w;
-    w.np = roundup(n, SP2_T);
+    w.np = roundup(n, SP2_PAD);
     w.ld = w.np;
-    w.nt = (int)(w.np / SP2_T);
-    w.ntri = w.nt * (w.nt + 1) / 2;
+    const int nt = (int)(w.np / SP2_T);
+    w.ntri = nt * (nt + 1) / 2;
     w.chunks = (int)(w.np / Sp2Cfg::KC);
-    int target = 144;                                  // lower tiles x k slices ~ this many workgroups (measured best at N = 510)
-    if (const char *e = getenv("JCDF_SP2_WORKGROUPS")) target = std::max(1, atoi(e));
-    const int want = std::max(1, std::min(w.chunks / 2, (target + w.ntri / 2) / w.ntri));
-    w.nsplit = want >= 8 ? 8 : want >= 4 ? 4 : want >= 2 ? 2 : 1;            // k_sp2_update is instantiated for these
-    w.slab_stride = w.np * w.ld;
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += roundup((int64_t)bytes, 256); return p; };
     w.Xa = (double *)take((size_t)w.np * w.ld * 8);
     w.Xb = (double *)take((size_t)w.np * w.ld * 8);
-    w.slabs = (double *)take((size_t)w.nsplit * w.slab_stride * 8);
     w.part = (double *)take(2 * 1024 * 8);
     w.partials = (double *)take((size_t)2 * 2 * SP2_PART * 8);
     w.state = (Sp2State *)take(2 * sizeof(Sp2State));
@@ -1158,25 +1152,9 @@ int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_
     hipLaunchKernelGGL(k_sp2_bounds, dim3(nb), dim3(256), 0, st, d_F, ldf, (int)n, w.part);
     hipLaunchKernelGGL(k_sp2_init, dim3((unsigned)w.np), dim3(256), 0, st, d_F, ldf, (int)n, (int)w.np, w.part, nb, w.Xa, w.ld, w.state,
                        w.partials);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_sp2_square, hipFuncAttributeMaxDynamicSharedMemorySize, Sp2Cfg::SMEM_BYTES);
-        attr_done = true;
-    }
-    for (int k = 0; k < iterations; ++k) {
-        hipLaunchKernelGGL(k_sp2_square, dim3((unsigned)(w.ntri * w.nsplit)), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.ld,
-                           w.nsplit, w.chunks, w.slabs, w.slab_stride, k);
-#define JCDF_SP2_UPDATE(NS)                                                                                                          \
-    hipLaunchKernelGGL(k_sp2_update<NS>, dim3((unsigned)(4 * w.ntri)), dim3(256), 0, st, w.Xa, w.Xb, w.Xa, w.Xb, w.ld, (int)n_occ,       \
-                       w.slabs, w.slab_stride, w.partials, (int)w.np, w.ntri, w.state, k)
-        switch (w.nsplit) {
-        case 1: JCDF_SP2_UPDATE(1); break;
-        case 2: JCDF_SP2_UPDATE(2); break;
-        case 4: JCDF_SP2_UPDATE(4); break;
-        default: JCDF_SP2_UPDATE(8); break;
-        }
-#undef JCDF_SP2_UPDATE
-    }
+    for (int k = 0; k < iterations; ++k)
+        hipLaunchKernelGGL(k_sp2_fused, dim3((unsigned)w.ntri), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb, w.ld,
+                           (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
     hipLaunchKernelGGL(k_sp2_finish, dim3((unsigned)std::min<int64_t>(n, 512)), dim3(256), 0, st, w.Xa, w.Xb, w.ld, (int)n, d_P, ldp,
                        w.state, (int)iterations, d_info);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;

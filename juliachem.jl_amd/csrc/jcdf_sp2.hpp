@@ -10,23 +10,25 @@
 // About 30-60 squarings of an N x N matrix: MFMA work on all CUs instead of the N dependent hand-offs of a
 // tridiagonalisation.  Optional path (scf flag density_solver = "sp2"); the eigensolver stays the default.
 //
-// Device program: k_sp2_bounds, k_sp2_init once; per squaring k_sp2_square (lower block-triangle of X^2 on the TN
-// MFMA core — X is symmetric, so X^2 = X^T X is the k-major SYRK of the K kernel — split-K into slabs) and
-// k_sp2_update (slab sum in slice order, X_{k+1} tile and its mirror image into the other X buffer).
-// tr X^2 = ||X||_F^2 for symmetric X, so the traces that steer iteration k are left by update k-1 as partial sums
-// and every workgroup of update k takes the same decision from them.  (A one-launch form — last slice to arrive
-// reduces — was slower: the device-scope release/acquire it needs writes back and invalidates the XCD's L2,
-// 14 us for a two-workgroup launch.)  No host round trip: the host launches a fixed number of iterations; after
-// convergence the remaining launches return at once.  The decision state is double-buffered by iteration parity
-// (iteration k reads state[k & 1], workgroup 0 writes state[(k + 1) & 1]).  n <= 4096.
+// Device program: k_sp2_bounds, k_sp2_init once, then ONE launch per squaring (k_sp2_fused): X is symmetric, so
+// X^2 = X^T X is the k-major SYRK of the K kernel — lower block-triangle of 32 x 32 tiles on the TN MFMA core, each
+// workgroup over the whole contraction length, the update as its epilogue.  tr X^2 = ||X||_F^2 for symmetric X, so the
+// two traces that steer squaring k are left by launch k-1 as per-tile partial sums and every workgroup of launch k
+// takes the same decision from them before X_k^2 exists.  No host round trip: the host launches a fixed number of
+// squarings; after convergence the remaining launches return at once.  The decision state is double-buffered by
+// iteration parity (launch k reads state[k & 1], tile 0 writes state[(k + 1) & 1]); the X buffer in use is the parity
+// of k.  n <= 4096.  Measured and dropped: 64 x 64 tiles with split-K — as two launches (square into slabs, update)
+// 24 us per squaring at N = 510 against 14 us (a launch that does nothing costs 5.4 us in a dependent chain), as one
+// launch whose last-arriving slice reduces 64 us (the device-scope release/acquire writes back and invalidates the L2).
 #pragma once
 #include "jcdf_gemm.hpp"
 
 namespace jcdf {
 
-typedef GemmCfg<2, 2, 2, 2, 32> Sp2Cfg;          // 64 x 64 tile, 4 waves of 32 x 32, 32 k rows per LDS stage
-constexpr int SP2_T = 64;
-constexpr int SP2_PART = 8448;                   // partial-sum slots per parity: padded rows (first launch) or 4 per lower tile
+typedef GemmCfg<1, 1, 2, 2, 32> Sp2Cfg;          // 32 x 32 tile, 4 waves of 16 x 16, 32 k rows per LDS stage
+constexpr int SP2_T = 32;                        // tile edge
+constexpr int SP2_PAD = 64;                      // matrices are padded to a multiple of this
+constexpr int SP2_PART = 8448;                   // partial-sum slots per parity: padded rows (first launch) or lower tiles
 
 struct Sp2State {
     int cur, phase, done, iters;                 // X buffer in use; 0 trace-guided, 1 = final 2X - X^2 pending; finished; squarings done
@@ -166,95 +168,60 @@ __device__ __forceinline__ void sp2_tile(int tile, int &ti, int &tj)
     tj = tile - ti * (ti + 1) / 2;
 }
 
-// slab[s][tile (ti >= tj)] = sum over the k chunks of slice s of X[k][ti-block]^T X[k][tj-block].
-// The X buffer in use is the parity of k (every squaring flips it); the state is not read here, so nothing stands
-// between the launch and the first operand loads — after convergence the remaining launches square for nothing.
-__global__ __launch_bounds__(Sp2Cfg::NT) void k_sp2_square(const double *__restrict__ Xa, const double *__restrict__ Xb, int64_t ld,
-                                                            int nsplit, int chunks, double *__restrict__ slabs, int64_t slab_stride, int k)
+// One squaring = ONE launch, no split-K: workgroup = one 32 x 32 lower tile over the whole contraction length, so the
+// tile it computes is final and the update (decision from the previous launch's partial sums, X_{k+1} tile, mirror image,
+// partial sums for the next launch) is its epilogue.  State, partial sums and the thread's own X elements are loaded
+// before the operand stream starts and used after it.
+
+__global__ __launch_bounds__(Sp2Cfg::NT) void k_sp2_fused(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
+                                                               double *Xb_w, int64_t ld, int n_occ, int chunks, double *partials,
+                                                               int npart0, int ntri, Sp2State *state, int k)
 {
     extern __shared__ __align__(16) double smem[];
-    const double *X = (k & 1) ? Xb : Xa;
-    const int tile = blockIdx.x / nsplit, s = blockIdx.x % nsplit;
-    int ti, tj;
-    sp2_tile(tile, ti, tj);
-    const int c0 = (int)((int64_t)chunks * s / nsplit), c1 = (int)((int64_t)chunks * (s + 1) / nsplit);
-    double4_t acc[Sp2Cfg::WM][Sp2Cfg::WN];
-#pragma unroll
-    for (int m = 0; m < Sp2Cfg::WM; ++m)
-#pragma unroll
-        for (int nn = 0; nn < Sp2Cfg::WN; ++nn) acc[m][nn] = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (c1 > c0)
-        gemm_tn_core<Sp2Cfg, false, 0, 2>(X + (int64_t)c0 * Sp2Cfg::KC * ld + ti * SP2_T, ld,
-                                          X + (int64_t)c0 * Sp2Cfg::KC * ld + tj * SP2_T, ld, c1 - c0, acc, smem);
-    double *out = slabs + (int64_t)s * slab_stride + (int64_t)(ti * SP2_T) * ld + tj * SP2_T;
-#pragma unroll
-    for (int m = 0; m < Sp2Cfg::WM; ++m)
-#pragma unroll
-        for (int nn = 0; nn < Sp2Cfg::WN; ++nn)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                out[(int64_t)tile_row<Sp2Cfg>(m, j) * ld + tile_col<Sp2Cfg>(nn)] = acc[m][nn][j];
-}
-
-// One workgroup per quarter (16 rows) of a lower tile: decision from the previous launch's partial sums, slab sum in
-// slice order, X_{k+1} rows + their mirror image into the other X buffer, partial sums of X_{k+1} for the next launch.
-// Every global load (state, partial sums, X, slabs) is issued before the first use of any of them: one round trip.
-template <int NS>
-__global__ __launch_bounds__(256) void k_sp2_update(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
-                                                    double *Xb_w, int64_t ld, int n_occ, const double *__restrict__ slabs,
-                                                    int64_t slab_stride, double *partials, int npart0, int ntri, Sp2State *state, int k)
-{
     __shared__ double red[2][256];
-    __shared__ double T[SP2_T][17];
     const double *X = (k & 1) ? Xb : Xa;
     double *Xn = (k & 1) ? Xa_w : Xb_w;
     const double *pin = partials + (int64_t)(k & 1) * 2 * SP2_PART;
     double *pout = partials + (int64_t)((k + 1) & 1) * 2 * SP2_PART;
-    const int tile = blockIdx.x >> 2, quarter = blockIdx.x & 3;
     int ti, tj;
-    sp2_tile(tile, ti, tj);
-    const int c2 = (threadIdx.x & 31) * 2, r0 = threadIdx.x >> 5;
-    // loads first
+    sp2_tile(blockIdx.x, ti, tj);
+    // state, partial sums and this thread's own X elements: issued before the operand stream, used after it
     const Sp2State st = state[k & 1];
-    double2_t x[2], q[2][NS];
-    int64_t off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        off[i] = (int64_t)(ti * SP2_T + 16 * quarter + r0 + 8 * i) * ld + tj * SP2_T + c2;
-        x[i] = *reinterpret_cast<const double2_t *>(X + off[i]);
-#pragma unroll
-        for (int h = 0; h < NS; ++h) q[i][h] = *reinterpret_cast<const double2_t *>(slabs + (int64_t)h * slab_stride + off[i]);
-    }
-    const int np_in = (k == 0) ? npart0 : 4 * ntri;
+    const int np_in = (k == 0) ? npart0 : ntri;
     double tx = 0.0, t2 = 0.0;
     for (int p = threadIdx.x; p < np_in; p += 256) {
         const double2_t v = *reinterpret_cast<const double2_t *>(pin + 2 * p);
         tx += v[0];
         t2 += v[1];
     }
+    const int col = tile_col<Sp2Cfg>(0);
+    double x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = X[(int64_t)(ti * SP2_T + tile_row<Sp2Cfg>(0, j)) * ld + tj * SP2_T + col];
     if (st.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) state[(k + 1) & 1] = st;
         return;
     }
+    double4_t acc[1][1];
+    acc[0][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_tn_core<Sp2Cfg, false, 0, 2>(X + ti * SP2_T, ld, X + tj * SP2_T, ld, chunks, acc, smem);
     const Sp2Decision d = sp2_decide(st, tx, t2, n_occ, red);
+    double (*T)[SP2_T + 1] = reinterpret_cast<double (*)[SP2_T + 1]>(smem);      // the GEMM stages are free now
     double ptr = 0.0, pfro = 0.0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rl = r0 + 8 * i, r = 16 * quarter + rl;               // row inside the quarter / inside the tile
-        double2_t sum = q[i][0];
-#pragma unroll
-        for (int h = 1; h < NS; ++h) sum += q[i][h];
-        const double2_t v = d.branch ? (2.0 * x[i] - sum) : sum;
-        *reinterpret_cast<double2_t *>(Xn + off[i]) = v;
-        T[c2][rl] = v[0];
-        T[c2 + 1][rl] = v[1];
-        pfro += v[0] * v[0] + v[1] * v[1];
-        if (ti == tj) ptr += (r == c2 ? v[0] : 0.0) + (r == c2 + 1 ? v[1] : 0.0);
+    for (int j = 0; j < 4; ++j) {
+        const int row = tile_row<Sp2Cfg>(0, j);
+        const double q = acc[0][0][j];
+        const double v = d.branch ? (2.0 * x[j] - q) : q;
+        Xn[(int64_t)(ti * SP2_T + row) * ld + tj * SP2_T + col] = v;
+        T[col][row] = v;
+        pfro += v * v;
+        if (ti == tj && row == col) ptr += v;
     }
     if (ti != tj) {
         __syncthreads();
-        const int c = threadIdx.x >> 2, rr = (threadIdx.x & 3) * 4;       // mirrored: row c of tile (tj, ti), 16 columns
-        double *dst = Xn + (int64_t)(tj * SP2_T + c) * ld + ti * SP2_T + 16 * quarter + rr;
+        const int c = threadIdx.x >> 3, rr = (threadIdx.x & 7) * 4;       // mirrored: row c of tile (tj, ti), 4 of its 32 columns
+        double *dst = Xn + (int64_t)(tj * SP2_T + c) * ld + ti * SP2_T + rr;
         *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
         *reinterpret_cast<double2_t *>(dst + 2) = double2_t{T[c][rr + 2], T[c][rr + 3]};
         pfro *= 2.0;
