@@ -217,6 +217,23 @@ int64_t jcdf_stedc_workspace_bytes(int64_t n);
 int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, double *d_Z, int64_t ldz,
                           void *d_work, int64_t work_bytes);
 
+/* Scalar tail of one SCF iteration, caller-side helper of the device SCF loop: E_elec = 1/2 sum D o (F + H)
+ * (SCF.jl:1116-1123) and ||D - D_old||_F from the four n x n device matrices, packed with the iteration's status words
+ * into d_out (8 doubles, device): {E_elec, ||dD||, *d_diis_flag, |*d_eig_err| + |*d_eig_info|, d_sp2_info[1],
+ * d_sp2_info[2], *d_pivot, d_sp2_info[0]} — any of the five status pointers may be NULL (read as 0).  Sums over a fixed
+ * partition in a fixed order (bit-reproducible).  d_work: 256 doubles of device memory. */
+int32_t jcdf_scf_tail_device(void *stream, int64_t n, const double *d_D, const double *d_D_old, const double *d_F, const double *d_H,
+                             const int32_t *d_diis_flag, const int32_t *d_eig_err, const int32_t *d_eig_info,
+                             const double *d_sp2_info, const double *d_pivot, double *d_work, double *d_out);
+
+/* Orthonormalise o <= 128 row vectors through their Gram matrix, caller-side helper of the SP2 step: d_Y (o x n
+ * row-major), d_G = Y Y^T (o x o, lower triangle read) -> d_L (o x o row-major) = Cholesky factor of G, d_Z (o x n
+ * row-major) = L^-1 Y (orthonormal rows with the span of Y's), d_pivot[0] = smallest diagonal element of L (<= 0: G was
+ * not positive definite and d_Z is meaningless).  Two launches (one workgroup factors in LDS; L^-1 Y by forward
+ * substitution, 16 columns per workgroup). */
+int32_t jcdf_orthonormalise_rows_device(void *stream, int64_t o, int64_t n, const double *d_G, const double *d_Y, double *d_Z,
+                                        double *d_L, double *d_pivot);
+
 /* Alternative to the eigensolve inside the SCF step (optional; SCF.jl:1072-1125 takes the density from eigen()):
  * the spectral projector P onto the n_occ lowest eigenvectors of the symmetric matrix d_F (n x n, device,
  * leading dimension ldf) by trace-correcting second-order spectral projection (csrc/jcdf_sp2.hpp) — matrix

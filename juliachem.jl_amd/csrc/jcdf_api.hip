@@ -10,6 +10,7 @@
 #include "jcdf_chol.hpp"
 #include "jcdf_dc.hpp"
 #include "jcdf_sp2.hpp"
+#include "jcdf_scf.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -1102,6 +1103,37 @@ int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int3
         return JCDF_ERR_INVALID;
     hipLaunchKernelGGL(k_diis_solve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_Bmat, d_dots, (int)nd, (int)head, (int)n,
                        (int)solve, d_coef, d_flag);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_scf_tail_device(void *stream, int64_t n, const double *d_D, const double *d_D_old, const double *d_F, const double *d_H,
+                             const int32_t *d_diis_flag, const int32_t *d_eig_err, const int32_t *d_eig_info, const double *d_sp2_info,
+                             const double *d_pivot, double *d_work, double *d_out)
+{
+    if (n < 1 || !d_D || !d_D_old || !d_F || !d_H || !d_work || !d_out) return JCDF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nn = n * n;
+    const int groups = (int)std::min<int64_t>(SCF_TAIL_GROUPS, (nn + 255) / 256);
+    hipLaunchKernelGGL(k_scf_tail_partial, dim3(groups), dim3(256), 0, st, d_D, d_D_old, d_F, d_H, nn, d_work);
+    hipLaunchKernelGGL(k_scf_tail_final, dim3(1), dim3(64), 0, st, d_work, groups, d_diis_flag, d_eig_err, d_eig_info, d_sp2_info, d_pivot,
+                       d_out);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_orthonormalise_rows_device(void *stream, int64_t o, int64_t n, const double *d_G, const double *d_Y, double *d_Z,
+                                        double *d_L, double *d_pivot)
+{
+    if (o < 1 || o > 128 || n < 1 || !d_G || !d_Y || !d_Z || !d_L || !d_pivot) return JCDF_ERR_INVALID;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
+        (void)hipFuncSetAttribute((const void *)k_trsm_small, hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 128 * 17) * 8);
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), (size_t)o * (o + 1) * 8, st, d_G, o, (int)o, d_L, o, d_pivot);
+    hipLaunchKernelGGL(k_trsm_small, dim3((unsigned)((n + 15) / 16)), dim3(256), ((size_t)o * (o + 1) + (size_t)o * 17) * 8, st, d_L, o,
+                       (int)o, d_Y, n, (int)n, d_Z, n);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

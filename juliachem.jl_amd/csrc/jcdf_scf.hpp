@@ -1,0 +1,143 @@
+// jcdf_scf.hpp — the scalar tail of one SCF iteration on the device (caller-side helper, like k_diis_solve):
+//   E_elec = 1/2 sum D o (F + H)      (SCF.jl:1116-1123)
+//   ||D - D_old||_F                   (SCF.jl:559-563 takes the rms of the same difference)
+// and the iteration's status words packed beside them, so that the host's ONE copy per iteration reads one 64-byte
+// record instead of the results of ~25 five-microsecond launches (sum, mul, norm, abs, casts, stack).
+// Two launches: per-workgroup partial sums over a fixed contiguous partition, then one workgroup adds them in index
+// order (bit-reproducible) and writes the record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jcdf {
+
+constexpr int SCF_TAIL_GROUPS = 128;
+
+__global__ __launch_bounds__(256) void k_scf_tail_partial(const double *__restrict__ D, const double *__restrict__ Dold,
+                                                          const double *__restrict__ F, const double *__restrict__ H, int64_t nn,
+                                                          double *__restrict__ part)
+{
+    __shared__ double red[2][256];
+    const int64_t per = (nn + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = per * blockIdx.x, hi = (lo + per < nn) ? lo + per : nn;
+    double e = 0.0, r = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const double d = D[i], dd = d - Dold[i];
+        e += d * (F[i] + H[i]);
+        r += dd * dd;
+    }
+    red[0][threadIdx.x] = e;
+    red[1][threadIdx.x] = r;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = red[0][0];
+        part[2 * blockIdx.x + 1] = red[1][0];
+    }
+}
+
+// out[0] = E_elec, out[1] = ||dD||_F, out[2] = DIIS flag, out[3] = eigensolver status (|err| + |info|),
+// out[4..7] = SP2 {finished, tr P, smallest pivot of the basis Cholesky, squarings}; absent inputs read as 0
+__global__ __launch_bounds__(64) void k_scf_tail_final(const double *__restrict__ part, int nparts, const int32_t *diis_flag,
+                                                       const int32_t *eig_err, const int32_t *eig_info, const double *sp2_info,
+                                                       const double *pivot, double *__restrict__ out)
+{
+    // one wave: lane l adds partials l, l + 64, ... then a butterfly — the same order on every run
+    double e = 0.0, r = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        e += part[2 * p];
+        r += part[2 * p + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o, 64);
+        r += __shfl_xor(r, o, 64);
+    }
+    if (threadIdx.x != 0) return;
+    out[0] = 0.5 * e;
+    out[1] = sqrt(r);
+    out[2] = diis_flag ? (double)*diis_flag : 0.0;
+    out[3] = (eig_err ? fabs((double)*eig_err) : 0.0) + (eig_info ? fabs((double)*eig_info) : 0.0);
+    out[4] = sp2_info ? sp2_info[1] : 0.0;
+    out[5] = sp2_info ? sp2_info[2] : 0.0;
+    out[6] = pivot ? *pivot : 0.0;
+    out[7] = sp2_info ? sp2_info[0] : 0.0;
+}
+
+}  // namespace jcdf
+
+namespace jcdf {
+
+// Orthonormalisation of o <= 128 row vectors through their Gram matrix (the SP2 step's basis: rocSOLVER potf2 +
+// rocBLAS trtri/trsm are ~20 launches and 0.17 ms there), two launches:
+//   k_chol_small  one workgroup: G = L L^T in LDS, right-looking, ONE barrier per column (the column is used unscaled by
+//                 the trailing update, every thread scaling by 1/sqrt(pivot) itself, and is scaled afterwards — no later
+//                 step reads it);  L (o x o row-major, lower) and pivot[0] = min diag L (<= 0: not positive definite)
+//   k_trsm_small  Z = L^-1 Y for 16 columns of Y (o x n) per workgroup: L and the column block in LDS, forward
+//                 substitution with one barrier per row.
+__global__ __launch_bounds__(256) void k_chol_small(const double *__restrict__ G, int64_t ldg, int o, double *__restrict__ L, int64_t ldl,
+                                                    double *__restrict__ pivot)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int lds = o + 1;
+    double *A = sm;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (int idx = tid; idx < o * o; idx += 256) {
+        const int i = idx / o, k = idx % o;
+        A[i * lds + k] = (k <= i) ? G[(int64_t)i * ldg + k] : 0.0;
+    }
+    double piv = 1e300;
+    for (int j = 0; j < o; ++j) {
+        __syncthreads();
+        if (j > 0) {                                              // scale the previous column now that nobody reads it unscaled
+            const double dp = A[(j - 1) * lds + (j - 1)];
+            const double ip = dp > 0.0 ? 1.0 / sqrt(dp) : 1.0;
+            for (int i = j + tid; i < o; i += 256) A[i * lds + (j - 1)] *= ip;
+        }
+        const double d = A[j * lds + j];
+        piv = fmin(piv, d > 0.0 ? sqrt(d) : -1.0);
+        const double inv2 = d > 0.0 ? 1.0 / d : 1.0;              // (l_ij / s)(l_kj / s) = l_ij l_kj / d
+        for (int i = j + 1 + ty; i < o; i += 16) {
+            const double lij = A[i * lds + j] * inv2;
+            for (int k = j + 1 + tx; k <= i; k += 16) A[i * lds + k] -= lij * A[k * lds + j];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < o * o; idx += 256) {
+        const int i = idx / o, k = idx % o;
+        double v = 0.0;
+        if (k < i) v = (k == o - 1) ? 0.0 : A[i * lds + k];       // columns < o-1 were scaled in the loop
+        if (k == i) { const double d = A[i * lds + i]; v = d > 0.0 ? sqrt(d) : 1.0; }
+        L[(int64_t)i * ldl + k] = v;
+    }
+    if (tid == 0) pivot[0] = piv;
+}
+
+__global__ __launch_bounds__(256) void k_trsm_small(const double *__restrict__ L, int64_t ldl, int o, const double *__restrict__ Y,
+                                                    int64_t ldy, int n, double *__restrict__ Z, int64_t ldz)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int lds = o + 1;
+    double *A = sm, *B = sm + (size_t)o * lds;                   // B: o x 17
+    const int tid = threadIdx.x, c = tid & 15, r0 = tid >> 4;
+    const int col = blockIdx.x * 16 + c;
+    for (int idx = tid; idx < o * o; idx += 256) {
+        const int i = idx / o, k = idx % o;
+        A[i * lds + k] = L[(int64_t)i * ldl + k];
+    }
+    for (int i = r0; i < o; i += 16) B[i * 17 + c] = (col < n) ? Y[(int64_t)i * ldy + col] : 0.0;
+    for (int j = 0; j < o; ++j) {
+        __syncthreads();
+        const double z = B[j * 17 + c] / A[j * lds + j];
+        if (r0 == 0 && col < n) Z[(int64_t)j * ldz + col] = z;
+        for (int i = j + 1 + r0; i < o; i += 16) B[i * 17 + c] -= A[i * lds + j] * z;
+    }
+}
+
+}  // namespace jcdf

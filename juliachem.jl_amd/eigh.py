@@ -103,6 +103,13 @@ class DeviceEigh:
             return torch.zeros((), dtype=torch.float64, device=self.device)
         return (self.work[1:2].view(torch.int32)[0].abs() + self.info[0].abs()).to(torch.float64)
 
+    def status_tensors(self):
+        """(int32 error word of the tridiagonalisation, int32 info of a vendor stedc) as 1-element device views, or
+        (None, None) when the plain torch path is in use — for `jcdf_scf_tail_device`."""
+        if not self.ok:
+            return None, None
+        return self.work[1:2].view(torch.int32)[0:1], self.info
+
     def check(self) -> bool:
         """True if the persistent kernel's grid barrier never timed out and stedc converged
         (reads two words from the device: call where the stream is synchronised anyway)."""

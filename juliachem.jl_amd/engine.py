@@ -177,7 +177,9 @@ class DeviceSCF:
         if self.density_solver == "sp2" and 0 < self.n_occ < self.N and self.N >= 2:
             from .eigh import DeviceSP2
             self.sp2 = DeviceSP2(self.N, self.n_occ, dev)
-        self.sp2_status = torch.zeros(4, dtype=torch.float64, device=dev)     # {finished, tr P, min pivot of the basis Cholesky, squarings}
+        self.sp2_pivot = None
+        self.tail_work = torch.zeros(256, dtype=torch.float64, device=dev)
+        self.tail_out = torch.zeros(8, dtype=torch.float64, device=dev)
         self.sp2_steps = self.sp2_fallbacks = 0
         self.sp2_two_pass = True
         self.sp2_reasons = {}
@@ -206,8 +208,8 @@ class DeviceSCF:
         self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.H.device)
         self.trail: List[Tuple[int, float, float, float]] = []
 
-    def _diag(self, use_sp2: bool = False) -> torch.Tensor:
-        """SCF.jl:1072-1125: F' = X F X, eigh, C = X U, D = 2 C_o C_o^T, E_elec."""
+    def _diag(self, use_sp2: bool = False) -> None:
+        """SCF.jl:1072-1125: F' = X F X, eigh, C = X U, D = 2 C_o C_o^T (the energy: _tail)."""
         Fp = self.X @ self.F @ self.X
         if use_sp2:
             # occupied-space projector P of F' by spectral projection; orthonormal basis of its range from the previous
@@ -215,17 +217,14 @@ class DeviceSCF:
             # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (checked through the pivots)
             P = self.sp2(Fp)
             Yt = self.Cp_t @ P                                      # (o, N) = (P Cp)^T
-            L, _ = torch.linalg.cholesky_ex(Yt @ Yt.T)
-            pivot = torch.diagonal(L).min()
-            Cp_t = torch.linalg.solve_triangular(L, Yt, upper=False)
+            Cp_t, pivot = self._orthonormalise(Yt)
             if self.sp2_two_pass:
                 # the new occupied space has turned far from the old one (small pivots, early iterations): Y^T Y is
                 # ill-conditioned and one Cholesky pass leaves Cp orthonormal only to cond * eps — second pass (CholQR2)
-                L2, _ = torch.linalg.cholesky_ex(Cp_t @ Cp_t.T)
-                Cp_t = torch.linalg.solve_triangular(L2, Cp_t, upper=False)
+                Cp_t, _ = self._orthonormalise(Cp_t)
             self.Cp_t = Cp_t
             self.Co_t = self.Cp_t @ self.X                          # (o, N): rows = occupied orbitals in the AO basis
-            self.sp2_status = torch.stack([self.sp2.info[1], self.sp2.info[2], pivot, self.sp2.info[0]])
+            self.sp2_pivot = pivot
             self.canonical = False
         else:
             self.eps, U = self.eigh(Fp)
@@ -234,7 +233,37 @@ class DeviceSCF:
             self.Co_t = self.C[:, :self.n_occ].T.contiguous()       # (o, N) row-major == (N, o) column-major
             self.canonical = True
         self.D = 2.0 * (self.Co_t.T @ self.Co_t)
-        return 0.5 * (torch.sum(self.D * self.F) + torch.sum(self.D * self.H))
+
+    def _orthonormalise(self, Yt: torch.Tensor):
+        """rows of Yt (o, N) -> L^-1 Yt with Yt Yt^T = L L^T; also the smallest pivot (1-element device tensor)"""
+        o = Yt.shape[0]
+        G = Yt @ Yt.T
+        if o <= 128:
+            Yt = Yt.contiguous()
+            Z = torch.empty_like(Yt)
+            L = torch.empty((o, o), dtype=torch.float64, device=Yt.device)
+            piv = torch.empty(1, dtype=torch.float64, device=Yt.device)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            rc = self._lib.jcdf_orthonormalise_rows_device(ctypes.c_void_p(torch.cuda.current_stream(Yt.device).cuda_stream), o,
+                                                           Yt.shape[1], p(G), p(Yt), p(Z), p(L), p(piv))
+            if rc != 0:
+                raise RuntimeError("jcdf_orthonormalise_rows_device failed (status %d)" % rc)
+            return Z, piv
+        L, _ = torch.linalg.cholesky_ex(G)
+        return torch.linalg.solve_triangular(L, Yt, upper=False), torch.diagonal(L).min().reshape(1)
+
+    def _tail(self, D_old: torch.Tensor, use_sp2: bool) -> List[float]:
+        """E_elec, ||D - D_old|| and the iteration's status words in one 64-byte record (`jcdf_scf_tail_device`), read
+        with ONE device-to-host copy — the only host synchronisation of the iteration."""
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        err, info = self.eigh.status_tensors()
+        rc = self._lib.jcdf_scf_tail_device(ctypes.c_void_p(torch.cuda.current_stream(self.H.device).cuda_stream), self.N,
+                                            p(self.D), p(D_old), p(self.F), p(self.H), p(self.diis_flag), p(err), p(info),
+                                            p(self.sp2.info) if use_sp2 else None, p(self.sp2_pivot) if use_sp2 else None,
+                                            p(self.tail_work), p(self.tail_out))
+        if rc != 0:
+            raise RuntimeError("jcdf_scf_tail_device failed (status %d)" % rc)
+        return self.tail_out.cpu().tolist()
 
     def canonical_orbitals(self) -> None:
         """Eigenvectors / eigenvalues of the current Fock matrix into self.C / self.eps (what the reference has after
@@ -318,40 +347,33 @@ class DeviceSCF:
                     self.B_dim = 2
         self._mark("diis")
         x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
-        F = (1.0 - x) * self.F_old + x * F
-        self.F = F
-        self.F_old = F.clone()
+        if x != 1.0:
+            F = (1.0 - x) * self.F_old + x * F
+        self.F = F.contiguous()
+        self.F_old = self.F.clone()
         D_old = self.D
         self._mark("damp")
         use_sp2 = self.sp2 is not None and not self.sp2_skip
-        E_elec = self._diag(use_sp2)
+        self._diag(use_sp2)
         self._mark("diag")
-        D_rms = torch.linalg.norm(self.D - D_old)
-        # ONE device-to-host copy (the only host sync of the iteration): energy, ||dD||, DIIS flag, eigensolver status
-        host = torch.cat([torch.stack([E_elec, D_rms, self.diis_flag[0].to(torch.float64), self.eigh.status()]),
-                          self.sp2_status]).cpu().tolist()
-        e_h, drms, faulty, eig_bad = host[:4]
+        e_h, drms, faulty, eig_bad, finished, trace, pivot, used = self._tail(D_old, use_sp2)
         if faulty:                                                 # "Faulty DIIS!" SCF.jl:493-499 (seen one sync later)
             self.B_dim = 2
             self.diis_flag.zero_()
         if use_sp2:
-            finished, trace, pivot, used = host[4:8]
             good = finished == 1.0 and abs(trace - self.n_occ) < 1e-6 and pivot > 1e-2 and math.isfinite(e_h)
-            self.sp2_two_pass = not (pivot > 0.9)                  # next iteration: the spaces turn smoothly
             self.sp2.adapt(used, finished == 1.0)
+            self.sp2_two_pass = not (pivot > 0.9)                  # next iteration: the spaces turn smoothly
             self.sp2_steps += 1
             if not good:                                           # not converged in the squarings enqueued / basis lost: eigensolve
                 self.sp2_fallbacks += 1
                 why = "unfinished" if finished != 1.0 else "trace" if abs(trace - self.n_occ) >= 1e-6 else "pivot" if not pivot > 1e-2 else "nan"
                 self.sp2_reasons[why] = self.sp2_reasons.get(why, 0) + 1
-                E_elec = self._diag(False)
-                D_rms = torch.linalg.norm(self.D - D_old)
-                e_h, drms, eig_bad = torch.stack([E_elec, D_rms, self.eigh.status()]).cpu().tolist()
+                self._diag(False)
+                e_h, drms, _, eig_bad = self._tail(D_old, False)[:4]
         if eig_bad and not self.eigh.check():                      # hand-off timeout / stedc failure: redo with the vendor solver
-            self.F = F
-            E_elec = self._diag()
-            D_rms = torch.linalg.norm(self.D - D_old)
-            e_h, drms = torch.stack([E_elec, D_rms]).cpu().tolist()
+            self._diag(False)
+            e_h, drms = self._tail(D_old, False)[:2]
         self.sp2_skip = not (drms < 15.0)       # occupied space still turning by ~90 degrees somewhere: no basis to project
         E = e_h + self.E_nuc
         dE = E - self.E_old

@@ -847,3 +847,40 @@ def test_scf_with_sp2_follows_the_eigensolver_trail(case, tol):
     n = b["Overlap"].shape[0]
     assert np.allclose(b["MO Coeff"].T @ b["Overlap"] @ b["MO Coeff"], np.eye(n), atol=1e-9)
     assert np.allclose(b["MO Coeff"].T @ b["Fock"] @ b["MO Coeff"], np.diag(b["Orbital Energies"]), atol=1e-8)
+
+
+@pytest.mark.parametrize("o,n,cond", [(1, 3, 1.0), (5, 17, 10.0), (64, 100, 1e3), (81, 510, 1e6), (128, 130, 1e2)])
+def test_orthonormalise_rows_kernel(o, n, cond):
+    """jcdf_orthonormalise_rows_device: Cholesky factor of the Gram matrix in one workgroup + L^-1 Y by forward
+    substitution, against LAPACK; pivot = min diag(L); a Gram matrix that is not positive definite shows in the pivot."""
+    import ctypes
+    import scipy.linalg
+    import torch
+    from juliachem_jl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(o)
+    U, _ = np.linalg.qr(rng.standard_normal((n, o)))
+    W, _ = np.linalg.qr(rng.standard_normal((o, o)))
+    Y = (W * np.geomspace(1.0, cond ** -0.5, o)) @ U.T            # o x n, singular values 1 .. cond^-1/2
+    G = Y @ Y.T
+    Yd, Gd = torch.as_tensor(Y, device=dev), torch.as_tensor(G, device=dev)
+    Z = torch.full((o, n), 7.0, dtype=torch.float64, device=dev)
+    L = torch.full((o, o), 7.0, dtype=torch.float64, device=dev)
+    piv = torch.zeros(1, dtype=torch.float64, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.jcdf_orthonormalise_rows_device(st, o, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 0
+    Lr = np.linalg.cholesky(G)
+    Lg, Zg = L.cpu().numpy(), Z.cpu().numpy()
+    assert np.all(np.triu(Lg, 1) == 0.0)
+    assert np.abs(Lg - Lr).max() < 1e-13 * cond ** 0.5
+    assert abs(piv.item() - np.diag(Lr).min()) < 1e-13 * cond ** 0.5
+    Zr = scipy.linalg.solve_triangular(Lr, Y, lower=True)
+    assert np.abs(Zg - Zr).max() < 1e-13 * cond
+    assert np.abs(Zg @ Zg.T - np.eye(o)).max() < 1e-14 * cond * o + 1e-13
+    assert lib.jcdf_orthonormalise_rows_device(st, 129, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 1      # JCDF_ERR_INVALID
+    if o >= 5:
+        Gd[2, 2] = -1.0
+        assert lib.jcdf_orthonormalise_rows_device(st, o, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 0
+        assert piv.item() <= 0.0

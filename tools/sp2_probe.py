@@ -42,8 +42,9 @@ orig = engine.DeviceSCF._diag
 log = []
 
 
-def patched(self):
-    E = orig(self)
+def patched(self, use_sp2=False):
+    orig(self, use_sp2)
+    E = 0.5 * torch.sum(self.D * (self.F + self.H))
     Fp = self.X @ self.F @ self.X
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -55,7 +56,6 @@ def patched(self):
     dE = (0.5 * (torch.sum(D2 * self.F) + torch.sum(D2 * self.H)) - E).item()
     eps = self.eps
     log.append((k, err, dE, dt * 1e3, lo, hi, (eps[self.n_occ] - eps[self.n_occ - 1]).item(), eps[0].item(), eps[-1].item()))
-    return E
 
 
 engine.DeviceSCF._diag = patched
