@@ -630,7 +630,7 @@ def test_rhf_run_water_dimer_screened_equals_dense():
     assert ref_s.converged and abs(scr["Energy"] - ref_s.energy) < 1e-9 and scr["Iterations"] == ref_s.iterations
 
 
-def _rhf_rank(rank, world, port, out):
+def _rhf_rank(rank, world, port, out, solver="eigh"):
     import json, os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch, torch.distributed as dist
@@ -642,13 +642,16 @@ def _rhf_rank(rank, world, port, out):
         g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
         atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
                                     for a in g["atoms"]]
-        res = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], {"dele": 1e-8, "rmsd": 1e-8, "niter": 60}, device=0)
+        res = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"],
+                      {"dele": 1e-8, "rmsd": 1e-8, "niter": 60, "density_solver": solver}, device=0)
+        assert res["Density Solver"]["name"] == solver and (solver == "eigh" or res["Density Solver"]["sp2_steps"] > 3)
         out.put((rank, res["Energy"], res["Iterations"], res["Timings"].non_timing_data["contraction_algorithm"]))
     finally:
         dist.destroy_process_group()
 
 
-def test_rhf_run_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("solver", ["eigh", "sp2"])
+def test_rhf_run_two_ranks_on_one_gpu(solver):
     """Two processes (gloo rehearsal of the RCCL job, both on the one GPU of the box): every rank computes the
     three-centre integrals of its own auxiliary shard only, blocks are exchanged, F is all-reduced; multi-rank runs take
     the screened layout (DensityFitting.jl:78-90).  Same energy as the single-rank screened run."""
@@ -660,7 +663,7 @@ def test_rhf_run_two_ranks_on_one_gpu():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_rhf_rank, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rhf_rank, args=(r, 2, port, out, solver)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -884,3 +887,34 @@ def test_orthonormalise_rows_kernel(o, n, cond):
         Gd[2, 2] = -1.0
         assert lib.jcdf_orthonormalise_rows_device(st, o, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 0
         assert piv.item() <= 0.0
+
+
+def test_scf_tail_record():
+    """jcdf_scf_tail_device: E_elec = 1/2 sum D o (F + H), ||D - D_old||_F and the status words, against torch; absent
+    status pointers read as zero; bit-reproducible."""
+    import ctypes
+    import torch
+    from juliachem_jl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = 137
+    D, Do, F, H = (torch.randn(n, n, dtype=torch.float64, generator=g).to(dev) for _ in range(4))
+    flag = torch.tensor([3], dtype=torch.int32, device=dev)
+    err = torch.tensor([-2], dtype=torch.int32, device=dev)
+    info = torch.tensor([5], dtype=torch.int32, device=dev)
+    sp2 = torch.tensor([41.0, 1.0, 81.0, 0, 0, 0, 0, 0], dtype=torch.float64, device=dev)
+    piv = torch.tensor([0.97], dtype=torch.float64, device=dev)
+    work = torch.zeros(256, dtype=torch.float64, device=dev)
+    out = torch.zeros(8, dtype=torch.float64, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.jcdf_scf_tail_device(st, n, p(D), p(Do), p(F), p(H), p(flag), p(err), p(info), p(sp2), p(piv), p(work), p(out)) == 0
+    o1 = out.cpu().numpy().copy()
+    E = 0.5 * (torch.sum(D * F) + torch.sum(D * H)).item()
+    assert abs(o1[0] - E) < 1e-10 * n and abs(o1[1] - torch.linalg.norm(D - Do).item()) < 1e-11
+    assert list(o1[2:]) == [3.0, 7.0, 1.0, 81.0, 0.97, 41.0]
+    assert lib.jcdf_scf_tail_device(st, n, p(D), p(Do), p(F), p(H), None, None, None, None, None, p(work), p(out)) == 0
+    o2 = out.cpu().numpy()
+    assert o2[0] == o1[0] and o2[1] == o1[1] and not o2[2:].any()
+    assert lib.jcdf_scf_tail_device(st, n, p(D), None, p(F), p(H), None, None, None, None, None, p(work), p(out)) == 1
