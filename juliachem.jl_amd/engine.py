@@ -174,7 +174,7 @@ class DeviceSCF:
         if self.density_solver not in ("eigh", "sp2"):
             raise ValueError("density_solver %r: \"eigh\" or \"sp2\"" % self.density_solver)
         self.sp2 = None
-        if self.density_solver == "sp2" and 0 < self.n_occ < self.N and self.N >= 2:
+        if self.density_solver == "sp2" and 0 < self.n_occ < self.N and 2 <= self.N <= 4096:     # outside: eigensolver
             from .eigh import DeviceSP2
             self.sp2 = DeviceSP2(self.N, self.n_occ, dev)
         self.sp2_pivot = None
@@ -191,6 +191,7 @@ class DeviceSCF:
         self.reset()
 
     def reset(self) -> None:
+        self.sp2_skip = True
         self.F = self.H.clone()
         self.D = torch.zeros_like(self.H)
         self._diag()                                               # "iteration 0", SCF.jl:178-181

@@ -16,7 +16,7 @@ from juliachem_jl_amd.engine import DeviceFockBuilder
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C20H42"
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 kept = float(sys.argv[3]) if len(sys.argv) > 3 else None      # Schwarz-kept pair fraction (band mask); None = dense map
-N, Q, o = synthetic.CONFIGS[cfg]
+N, Q, o = (tuple(int(x) for x in cfg.split(",")) if "," in cfg else synthetic.CONFIGS[cfg])      # name or N,Q,o
 rng = np.random.default_rng(1)
 dev = torch.device("cuda", 0)
 pq = (None, None)
