@@ -2,6 +2,9 @@
 """Extracts the golden DATA of the reference's own run logs into tests/golden/*.json:
   /root/reference/water_ccpvdz_out.log        -> water_ccpvdz_rifit.json   (SURVEY 8c golden #1)
   /root/reference/test/water_new_algo-4-8.log -> water_631g2dfp_jkfit.json (golden #2: sp shells, f and g functions)
+  /root/reference/test/s10_new_algo-3-20.log  -> s22_10_benzene_methane_631g2dfp_jkfit.json (golden #3: the third run
+      in that log, S22 complex 10 benzene...methane, 17 atoms with carbon, 297 AO / 1022 aux, 3 MPI ranks; the log stops
+      after the second printed iteration, so the trail has two lines and there is no final energy)
 basis + auxiliary basis exponents/coefficients as printed, the COM-shifted geometry in bohr, SCF
 settings, the printed iteration trail (iter, E, dE, Drms) and the final energy.
 Numbers only — no reference source text is copied.  Run in the build container
@@ -15,7 +18,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests",
 CASES = [("/root/reference/water_ccpvdz_out.log", "water_ccpvdz_rifit.json",
           "water_ccpvdz_out.log (JuliaChem.jl reference run; lines 44-157, 196-198, 205-216, 253-523, 563)"),
          ("/root/reference/test/water_new_algo-4-8.log", "water_631g2dfp_jkfit.json",
-          "test/water_new_algo-4-8.log (JuliaChem.jl reference run; lines 48-202, 226-228, 244-255, 264-283)")]
+          "test/water_new_algo-4-8.log (JuliaChem.jl reference run; lines 48-202, 226-228, 244-255, 264-283)"),
+         ("/root/reference/test/s10_new_algo-3-20.log", "s22_10_benzene_methane_631g2dfp_jkfit.json",
+          "test/s10_new_algo-3-20.log (JuliaChem.jl reference run 3 of the file; lines 638-1576, 1587-1603, 1616-1633)", 599)]
 AM = {"S": 0, "P": 1, "D": 2, "F": 3, "G": 4}
 
 
@@ -42,8 +47,8 @@ def parse_basis(lines):
     return atoms
 
 
-def extract(LOG, OUT, source):
-    txt = open(LOG).read().splitlines()
+def extract(LOG, OUT, source, first_line=0):
+    txt = open(LOG).read().splitlines()[first_line:]
     i_aux = next(i for i, l in enumerate(txt) if "Printing Auxillary basis set" in l)
     i_meta = next(i for i, l in enumerate(txt) if "Printing basis set metadata" in l)
     i_bas = next(i for i, l in enumerate(txt) if "Printing basis set..." in l)
@@ -51,7 +56,8 @@ def extract(LOG, OUT, source):
     aux = parse_basis(txt[i_aux:i_meta])
     i_xyz = next(i for i, l in enumerate(txt) if "in xyz format" in l)
     geom = []
-    for l in txt[i_xyz:i_xyz + 12]:
+    i_end = next(i for i, l in enumerate(txt) if "END COORDINATE ANALYSIS" in l)
+    for l in txt[i_xyz:i_end]:
         m = re.match(r"^([A-Z][a-z]?)\s+([-\d.eE]+)\s+([-\d.eE]+)\s+([-\d.eE]+)\s*$", l)
         if m:
             geom.append({"symbol": m.group(1), "center": [float(m.group(k)) for k in (2, 3, 4)]})
@@ -60,7 +66,7 @@ def extract(LOG, OUT, source):
         m = re.match(r"^(\d+)\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})\s+(-?\d+\.\d{10})(\s+\d+\.\d{10})?\s*$", l)
         if m:
             trail.append([int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))])
-    e_final = float(next(re.search(r"Total SCF Energy: (-?[\d.]+) h", l).group(1) for l in txt if "Total SCF Energy" in l))
+    e_final = next((float(re.search(r"Total SCF Energy: (-?[\d.]+) h", l).group(1)) for l in txt if "Total SCF Energy" in l), None)
     meta = {}
     for l in txt:
         for key in ("Number of basis functions", "Number of auxillary basis functions", "Number of electrons",
@@ -71,7 +77,7 @@ def extract(LOG, OUT, source):
     out = {"source": source,
            "units": "bohr (COM-shifted, as printed)", "atoms": geom,
            "basis": {a["symbol"]: a["shells"] for a in prim}, "aux_basis": {a["symbol"]: a["shells"] for a in aux},
-           "atom_order": [a["symbol"] for a in prim], "charges": {"O": 8, "H": 1},
+           "atom_order": [a["symbol"] for a in prim], "charges": {k: v for k, v in {"H": 1, "C": 6, "O": 8}.items() if any(a["symbol"] == k for a in prim)},
            "settings": meta, "trail": trail, "final_energy": e_final}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     json.dump(out, open(OUT, "w"), indent=1)
@@ -80,8 +86,8 @@ def extract(LOG, OUT, source):
 
 
 def main():
-    for log, name, source in CASES:
-        extract(log, os.path.join(GOLDEN, name), source)
+    for log, name, source, *first in CASES:
+        extract(log, os.path.join(GOLDEN, name), source, *first)
 
 
 if __name__ == "__main__":
