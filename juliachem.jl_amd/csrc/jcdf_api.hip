@@ -691,13 +691,32 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     const int nT = h->n_ntiles;
     h->ntri = nT * (nT + 1) / 2;
     const int64_t Ktot = h->Ql * h->o;
-    // Split-K: all tiles of one k-slice run on one XCD (they share W rows through that L2), so
-    // the slice count is a multiple of 8 and sized so that ntri * S/8 workgroups fill, but do
-    // not exceed, one XCD's residency (2 workgroups per CU): every workgroup is resident in a
-    // single round and all finish together.
+    // Split-K: all tiles of one k-slice run on one XCD (they share W rows through that L2), so the slice count is a
+    // multiple of 8: m slices per XCD.  Measured (tools/prof_fock.py, JCDF_K_SLICES_PER_XCD): when the lower triangle has
+    // at most one tile per CU of an XCD, the best m is the largest for which all ntri * m workgroups are resident at once
+    // (2 per CU; N = 510: m = 6 0.91 ms, m = 8 1.18, m = 16 1.18 — a partial second round costs more than it balances);
+    // with more tiles than that a single round leaves some CUs with two workgroups and the rest with one (N = 956:
+    // m = 1 9.2 ms), and many short rounds balance better (m = 8 6.7 ms; N = 1250: 19.9 -> 18.3 ms).  Model: busiest
+    // CU's workgroup count / m; multi-round forms are considered only when one slice per XCD is already more than one
+    // workgroup per CU (N = 896, 28 tiles: m = 2 in one round 2.4 ms, m = 8 2.8 ms), charged 5 %, taken when they win by 5 %.
     const int64_t max_chunks = std::max<int64_t>(1, Ktot / (4 * KC));      // >= 4 LDS stages per slice
-    const int64_t slots_per_xcd = 2 * std::max(1, h->num_cu / 8);
+    static const double K_MULTI_ROUND_CHARGE = [] { const char *e = getenv("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.05; }();
+    const int64_t cus_per_xcd = std::max(1, h->num_cu / 8);
+    const int64_t slots_per_xcd = 2 * cus_per_xcd;
     int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ntri);
+    {
+        const int64_t w1 = h->ntri * per_xcd;                              // single round
+        const double single = (double)((w1 + cus_per_xcd - 1) / cus_per_xcd) / (double)per_xcd;
+        double best = 1e300;
+        int64_t best_m = 0;
+        for (int64_t m = 4; m <= 12 && h->ntri > cus_per_xcd; ++m) {
+            if (h->ntri * m <= slots_per_xcd || 8 * m > max_chunks || 8 * m * h->ntri * 128 * 128 * 8 > (int64_t)512 << 20) continue;
+            const double cost = K_MULTI_ROUND_CHARGE * (double)((h->ntri * m + cus_per_xcd - 1) / cus_per_xcd) / (double)m;
+            if (cost <= best) { best = cost; best_m = m; }                 // ties: the finer split
+        }
+        if (best_m && best < 0.95 * single) per_xcd = best_m;
+        if (const char *e = getenv("JCDF_K_SLICES_PER_XCD")) per_xcd = std::max(1, atoi(e));
+    }
     int64_t S = 8 * per_xcd;
     if (S > max_chunks) S = std::max<int64_t>(1, max_chunks);
     h->KS = (int)roundup((Ktot + S - 1) / S, KC);
