@@ -186,9 +186,11 @@ def main():
             scf2.step()
         barrier()
         ta = time.perf_counter()
-        alt_fock = []
+        alt_fock, alt_k = [], {}
         for _ in range(args.steps):
             scf2.step()
+            for ks in fb.h.kernel_stats():
+                alt_k.setdefault(ks["name"], []).append(ks["seconds"])
             alt_fock.append(fb.h.synchronize().fock_time)
         barrier()
         alt_s = time.perf_counter() - ta
@@ -197,7 +199,8 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             alt_s = float(tt.item())
         alt = {"density_solver": "sp2", "value": args.steps / alt_s, "unit": "SCF iterations/s", "ms_per_step": alt_s / args.steps * 1e3,
-               "steps": args.steps, "fock_build_ms": float(np.mean(alt_fock)) * 1e3, "sp2_steps": scf2.sp2_steps, "sp2_fallbacks": scf2.sp2_fallbacks,
+               "steps": args.steps, "fock_build_ms": float(np.mean(alt_fock)) * 1e3,
+               "kernels_ms": {k: float(np.mean(v)) * 1e3 for k, v in alt_k.items()}, "sp2_steps": scf2.sp2_steps, "sp2_fallbacks": scf2.sp2_fallbacks,
                "energy_minus_eigh": scf2.trail[-1][1] - scf.trail[-1][1],
                "note": "optional scf flag density_solver=sp2: occupied-space projector by matrix squarings (jcdf_sp2_device) instead "
                        "of the per-iteration eigensolve; same energies; not the default, not `value`"}
