@@ -698,9 +698,10 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     // with more tiles than that a single round leaves some CUs with two workgroups and the rest with one (N = 956:
     // m = 1 9.2 ms), and many short rounds balance better (m = 8 6.7 ms; N = 1250: 19.9 -> 18.3 ms).  Model: busiest
     // CU's workgroup count / m; multi-round forms are considered only when one slice per XCD is already more than one
-    // workgroup per CU (N = 896, 28 tiles: m = 2 in one round 2.4 ms, m = 8 2.8 ms), charged 5 %, taken when they win by 5 %.
+    // workgroup per CU (N = 896, 28 tiles: m = 2 in one round 2.4 ms, m = 8 2.8 ms) and taken when the model says they win
+    // (N = 1915, 120 tiles: m = 1 66 ms, m = 4 60 ms).
     const int64_t max_chunks = std::max<int64_t>(1, Ktot / (4 * KC));      // >= 4 LDS stages per slice
-    static const double K_MULTI_ROUND_CHARGE = [] { const char *e = getenv("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.05; }();
+    static const double K_MULTI_ROUND_CHARGE = [] { const char *e = getenv("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.0; }();
     const int64_t cus_per_xcd = std::max(1, h->num_cu / 8);
     const int64_t slots_per_xcd = 2 * cus_per_xcd;
     int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ntri);
@@ -714,7 +715,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
             const double cost = K_MULTI_ROUND_CHARGE * (double)((h->ntri * m + cus_per_xcd - 1) / cus_per_xcd) / (double)m;
             if (cost <= best) { best = cost; best_m = m; }                 // ties: the finer split
         }
-        if (best_m && best < 0.95 * single) per_xcd = best_m;
+        if (best_m && best < 0.99 * single) per_xcd = best_m;
         if (const char *e = getenv("JCDF_K_SLICES_PER_XCD")) per_xcd = std::max(1, atoi(e));
     }
     int64_t S = 8 * per_xcd;
