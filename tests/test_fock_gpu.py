@@ -918,3 +918,20 @@ def test_scf_tail_record():
     o2 = out.cpu().numpy()
     assert o2[0] == o1[0] and o2[1] == o1[1] and not o2[2:].any()
     assert lib.jcdf_scf_tail_device(st, n, p(D), None, p(F), p(H), None, None, None, None, None, p(work), p(out)) == 1
+
+
+@pytest.mark.parametrize("m", [1, 3, 8])
+def test_exchange_split_k_is_result_invariant(m, monkeypatch):
+    """The K kernel's split-K slice count (8 x JCDF_K_SLICES_PER_XCD; chosen by jcdf_configure from the tile count)
+    changes the summation tree only: same F to roundoff for any of them, rows beyond the contraction length are zero."""
+    N, Q, o = 300, 96, 81
+    s = synthetic.make(N, Q, o, seed=13)
+    B = orc.calculate_B(s.J2c, s.T)
+    ref = s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :o])
+    monkeypatch.setenv("JCDF_K_SLICES_PER_XCD", str(m))
+    h = _handle(N, Q, 0, Q, o)
+    h.set_B(np.asfortranarray(B.reshape(Q, N * N, order="F")))
+    h.set_core_hamiltonian(s.H)
+    F, _ = h.fock_build(s.C[:, :o])
+    assert _rel(F, ref) < RTOL and np.array_equal(F, F.T)
+    h.close()
