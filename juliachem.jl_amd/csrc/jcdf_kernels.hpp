@@ -145,10 +145,23 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
 // pass streams half of B).  HBM-bound, no MFMA.  Also finalises V.
 // Reference: calculate_J_screened_GPU (GPUDF.jl:544-547) / DenseGPUDF.jl:103.
 // ---------------------------------------------------------------------------
-constexpr int J_ROWS = 8;      // q rows per workgroup: 8 rows x Np doubles contiguous per aux index
-constexpr int J_QUNROLL = 2;   // aux indices in flight per thread (x J_ROWS loads of 16 B)
+// Register budget: beside the K kernel (two 216-VGPR waves per SIMD) 80 of a SIMD's 512 registers are free, so this kernel
+// must stay <= 80 VGPRs to run WHILE K runs (J beside K) and wants as many loads in flight as that allows:
+// 4 rows x 3 aux indices = 12 loads of 16 B, 71 VGPRs.  (8 rows x 2: 86 VGPRs, not resident beside K; 8 x 1: 58 VGPRs,
+// resident but latency-starved; 8 x 2 forced to 80: spills.)
+#ifndef JCDF_J_ROWS
+#define JCDF_J_ROWS 4
+#endif
+constexpr int J_ROWS = JCDF_J_ROWS;      // q rows per workgroup: J_ROWS rows x Np doubles contiguous per aux index
+#ifndef JCDF_J_QUNROLL
+#define JCDF_J_QUNROLL 3
+#endif
+constexpr int J_QUNROLL = JCDF_J_QUNROLL;   // aux indices in flight per thread (x J_ROWS loads of 16 B)
 
-__global__ __launch_bounds__(256) void k_coulomb_J(
+#ifndef JCDF_J_BLOCKS_PER_CU
+#define JCDF_J_BLOCKS_PER_CU 6
+#endif
+__global__ __launch_bounds__(256, JCDF_J_BLOCKS_PER_CU) void k_coulomb_J(
     const double *__restrict__ B, const double *__restrict__ vpart, int nvp, int Ql, int Nk, int Np,
     int QS, double *__restrict__ Jpart, double *__restrict__ V, const unsigned long long *__restrict__ jmask)
 {
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(256) void k_coulomb_J(
 #pragma unroll
         for (int r = 0; r < J_ROWS; ++r) acc[r] = double2_t{0.0, 0.0};
         int k = 0;
+#pragma unroll 1
         for (; k + J_QUNROLL <= nQ; k += J_QUNROLL) {
             double2_t v[J_QUNROLL][J_ROWS];
 #pragma unroll
