@@ -47,25 +47,22 @@ struct jcdf_handle {
 
     // sizes
     int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
-    int64_t Nk = 0, Np = 0;
-    int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_ntiles = 0, nvp = 0;
+    int64_t Np = 0, ldq = 0, Wld = 0, Plow = 0;
+    int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_qt = 0, vld = 0;
+    int n_chunks = 0, n_stages = 0;
     int ntri = 0, S = 0, KS = 0;
-    int SJ = 0, QS = 0;
-    int64_t Wrows = 0;
     bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
     bool dense_map = true;
 
     // device buffers
-    double *dB = nullptr, *dCpad = nullptr, *dCperm = nullptr, *dW = nullptr, *dVpart = nullptr, *dV = nullptr;
-    double *dJpart = nullptr, *dKslab = nullptr, *dH = nullptr, *dF = nullptr, *dC = nullptr;
-    double *dLinvT = nullptr;
+    double *dB = nullptr, *dCpad = nullptr, *dCv = nullptr, *dWt = nullptr, *dVpart = nullptr, *dV = nullptr;
+    double *dJ = nullptr, *dKslab = nullptr, *dH = nullptr, *dF = nullptr, *dC = nullptr;
+    double *dLinv = nullptr;                             // rows [q0,q1) of L^-1, row-major (s contiguous)
     int64_t ldl = 0, linv_rows = 0;
-    int64_t *dpq_p = nullptr, *dpq_q = nullptr;
-    int *dWkptr = nullptr, *dWklist = nullptr;          // block-sparse stage lists of the W kernel (null: dense)
-    unsigned long long *dJmask = nullptr;               // per J row block: non-empty 128-column tiles
-    double kept_tile_fraction = 1.0;
-    double *dRaw = nullptr, *dTint = nullptr;      // setup staging (chunked), freed after setup
-    int64_t stage_rows = 0;
+    int *dWchunk = nullptr, *dStgC = nullptr, *dStgQ = nullptr, *dStgP = nullptr;   // stage table of the W kernel
+    int *dJrow = nullptr, *dCmap = nullptr;              // packed rows with q >= p; (q,p) -> index into J
+    double *dStage = nullptr;                            // setup staging for pushed three-centre blocks, freed after setup
+    int64_t stage_doubles = 0;
     int64_t bytes = 0;
 
     // timing
@@ -89,6 +86,8 @@ namespace {
         }                                                                                    \
     } while (0)
 
+hipError_t ensure_device_attributes();
+
 int32_t fail(jcdf_handle *h, int32_t code, const std::string &msg)
 {
     if (h) h->err = msg;
@@ -111,6 +110,15 @@ int32_t dev_alloc(jcdf_handle *h, T **p, int64_t count, bool zero)
 }
 
 template <class T>
+int32_t dev_upload(jcdf_handle *h, T **p, const std::vector<T> &v)
+{
+    int32_t rc = dev_alloc(h, p, (int64_t)std::max<size_t>(v.size(), 1), false);
+    if (rc) return rc;
+    if (!v.empty()) JCDF_HIP(h, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return JCDF_OK;
+}
+
+template <class T>
 void dev_free(jcdf_handle *h, T **p, int64_t count)
 {
     if (*p) {
@@ -123,120 +131,124 @@ void dev_free(jcdf_handle *h, T **p, int64_t count)
 void free_all(jcdf_handle *h)
 {
     (void)hipSetDevice(h->device);
-    double **bufs[] = {&h->dB, &h->dCpad, &h->dCperm, &h->dW, &h->dVpart, &h->dV, &h->dJpart, &h->dKslab,
-                       &h->dH, &h->dF, &h->dC, &h->dLinvT, &h->dRaw, &h->dTint};
+    double **bufs[] = {&h->dB, &h->dCpad, &h->dCv, &h->dWt, &h->dVpart, &h->dV, &h->dJ, &h->dKslab,
+                       &h->dH, &h->dF, &h->dC, &h->dLinv, &h->dStage};
     for (auto b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    if (h->dpq_p) { (void)hipFree(h->dpq_p); h->dpq_p = nullptr; }
-    if (h->dpq_q) { (void)hipFree(h->dpq_q); h->dpq_q = nullptr; }
-    if (h->dWkptr) { (void)hipFree(h->dWkptr); h->dWkptr = nullptr; }
-    if (h->dWklist) { (void)hipFree(h->dWklist); h->dWklist = nullptr; }
-    if (h->dJmask) { (void)hipFree(h->dJmask); h->dJmask = nullptr; }
+    int **ibufs[] = {&h->dWchunk, &h->dStgC, &h->dStgQ, &h->dStgP, &h->dJrow, &h->dCmap};
+    for (auto b : ibufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     h->recs.clear();
     h->bytes = 0;
+    h->stage_doubles = 0;
     h->configured = h->have_metric = h->have_B = h->have_H = h->pushed_any = false;
 }
 
 // ---- W kernel dispatch: WMw 16-orbital MFMA row tiles per wave, WVMw wave rows ------------
 template <int WM, int WVM>
-void launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
+hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
     using Cfg = WCfg<WM, WVM>;
-    if (set_attr_only) {
-        (void)hipFuncSetAttribute((const void *)k_exchange_W<WM, WVM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Cfg::SMEM_BYTES);
-        return;
-    }
-    const int64_t outer = h->Ql * h->n_ntiles;
-    const int64_t nblk = roundup(outer, 8) * h->n_mtiles;
-    hipLaunchKernelGGL((k_exchange_W<WM, WVM>), dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB,
-                       h->dCpad, h->dCperm, h->dW, h->dVpart, (int)h->Ql, (int)h->o, (int)h->Nk, (int)h->Np,
-                       h->opad, h->n_mtiles, h->n_ntiles, h->dWkptr, h->dWklist);
+    if (set_attr_only)     // per device: jcdf_configure runs on the handle's device
+        return hipFuncSetAttribute((const void *)k_exchange_W<WM, WVM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Cfg::SMEM_BYTES);
+    const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
+    hipLaunchKernelGGL((k_exchange_W<WM, WVM>), dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::SMEM_BYTES, st, h->dB, h->ldq,
+                       h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP);
+    return hipSuccess;
 }
 
-void launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
+hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
     if (h->WVMw == 2) {
         switch (h->WMw) {
-            case 5: launch_W_t<5, 2>(h, st, attr); break;
-            case 6: launch_W_t<6, 2>(h, st, attr); break;
-            case 7: launch_W_t<7, 2>(h, st, attr); break;
-            default: launch_W_t<8, 2>(h, st, attr); break;
+            case 5: return launch_W_t<5, 2>(h, st, attr);
+            case 6: return launch_W_t<6, 2>(h, st, attr);
+            case 7: return launch_W_t<7, 2>(h, st, attr);
+            default: return launch_W_t<8, 2>(h, st, attr);
         }
-        return;
     }
     switch (h->WMw) {
-        case 1: launch_W_t<1, 1>(h, st, attr); break;
-        case 2: launch_W_t<2, 1>(h, st, attr); break;
-        case 3: launch_W_t<3, 1>(h, st, attr); break;
-        case 4: launch_W_t<4, 1>(h, st, attr); break;
-        case 5: launch_W_t<5, 1>(h, st, attr); break;
-        case 6: launch_W_t<6, 1>(h, st, attr); break;
-        case 7: launch_W_t<7, 1>(h, st, attr); break;
-        default: launch_W_t<8, 1>(h, st, attr); break;
+        case 1: return launch_W_t<1, 1>(h, st, attr);
+        case 2: return launch_W_t<2, 1>(h, st, attr);
+        case 3: return launch_W_t<3, 1>(h, st, attr);
+        case 4: return launch_W_t<4, 1>(h, st, attr);
+        case 5: return launch_W_t<5, 1>(h, st, attr);
+        case 6: return launch_W_t<6, 1>(h, st, attr);
+        case 7: return launch_W_t<7, 1>(h, st, attr);
+        default: return launch_W_t<8, 1>(h, st, attr);
     }
 }
 
-KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t st)
+// every hip* status of a build is folded into one word and reported by enqueue_fock
+struct HipAcc {
+    hipError_t first = hipSuccess;
+    void operator()(hipError_t e) { if (first == hipSuccess && e != hipSuccess) first = e; }
+};
+
+KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t st, HipAcc &ok)
 {
     while (h->recs.size() <= idx) {
         KernelRec r{};
-        (void)hipEventCreate(&r.e0);
-        (void)hipEventCreate(&r.e1);
+        ok(hipEventCreate(&r.e0));
+        ok(hipEventCreate(&r.e1));
         h->recs.push_back(r);
     }
     KernelRec &r = h->recs[idx];
     r.name = name;
     r.flops = r.alg_flops = r.alg_bytes = 0.0;
-    (void)hipEventRecord(r.e0, st);
+    ok(hipEventRecord(r.e0, st));
     return r;
 }
 
 int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t st)
 {
-    const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o;
+    const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o, P = (double)h->P;
+    HipAcc ok;
     size_t k = 0;
-    (void)hipEventRecord(h->ev_begin, st);
+    ok(hipEventRecord(h->ev_begin, st));
     {
-        KernelRec &r = rec_begin(h, k++, "k_prep_C", st);
+        KernelRec &r = rec_begin(h, k++, "k_prep_C", st, ok);
         const int64_t tot = h->Np * h->opad;
         hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
-                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles * h->WVMw, h->dCpad, h->dCperm);
+                           (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles * h->WVMw, h->dCpad, h->dCv);
         r.alg_bytes = 8.0 * N * o;
-        (void)hipEventRecord(r.e1, st);
+        ok(hipEventRecord(r.e1, st));
     }
     {
-        KernelRec &r = rec_begin(h, k++, "k_exchange_W", st);
-        launch_W(h, st);
-        r.flops = 2.0 * Ql * (double)h->Nk * (double)h->Np * (double)h->opad * h->kept_tile_fraction;
-        r.alg_flops = 2.0 * Ql * N * N * o + 2.0 * Ql * N * o;      // W (+ fused V from W)
-        r.alg_bytes = 8.0 * Ql * N * N + 8.0 * Ql * o * N;           // B read once + W written once
-        (void)hipEventRecord(r.e1, st);
+        KernelRec &r = rec_begin(h, k++, "k_exchange_W", st, ok);
+        ok(launch_W(h, st));
+        const int nparts = h->n_chunks * h->n_mtiles;
+        hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 255) / 256)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
+                           (int)h->Ql, (int)h->ldq, h->dV);
+        r.flops = 2.0 * 16.0 * (double)h->n_stages * (double)h->opad * (double)h->n_qt * TILE_Q;   // incl. all padding
+        r.alg_flops = 2.0 * Ql * P * o + 2.0 * Ql * N * o;           // the reference's 2 Q P o (+ fused V from W)
+        r.alg_bytes = 8.0 * Ql * P + 8.0 * Ql * o * N;               // B read once + W written once
+        ok(hipEventRecord(r.e1, st));
     }
     auto run_J = [&](size_t slot, hipStream_t st) {
-        KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st);
-        hipLaunchKernelGGL(k_coulomb_J, dim3((unsigned)((h->N + J_ROWS - 1) / J_ROWS), (unsigned)h->SJ), dim3(256),
-                           (size_t)h->QS * sizeof(double), st, h->dB, h->dVpart, h->nvp, (int)h->Ql,
-                           (int)h->Nk, (int)h->Np, h->QS, h->dJpart, h->dV, h->dJmask);
-        r.flops = r.alg_flops = Ql * N * (N + 1.0);
-        r.alg_bytes = 8.0 * Ql * N * (N + 1.0) / 2.0;               // lower triangle of B, once
-        (void)hipEventRecord(r.e1, st);
+        KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st, ok);
+        const int64_t groups = (h->Plow + 4 * J_ROWS - 1) / (4 * J_ROWS);
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)h->num_cu * JCDF_J_BLOCKS_PER_CU));
+        hipLaunchKernelGGL(k_coulomb_J, dim3(grid), dim3(256), (size_t)h->ldq * sizeof(double), st, h->dB, h->ldq, h->dV,
+                           h->dJrow, h->Plow, h->dJ);
+        r.flops = r.alg_flops = 2.0 * Ql * (double)h->Plow;
+        r.alg_bytes = 8.0 * Ql * (double)h->Plow;                    // the kept pairs with q >= p, once
+        ok(hipEventRecord(r.e1, st));
     };
     auto run_K = [&](size_t slot) {
-        KernelRec &r = rec_begin(h, slot, "k_exchange_K", st);
+        KernelRec &r = rec_begin(h, slot, "k_exchange_K", st, ok);
         const int nblk = (int)(roundup(h->S, 8) * h->ntri);
-        static const bool k4 = [] { const char *e = getenv("JCDF_K_VARIANT"); return !(e && atoi(e) == 0); }();
-        if (k4)
-            hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), KCfg4::SMEM_BYTES, st, h->dW,
-                               (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
-        else
-            hipLaunchKernelGGL(k_exchange_K<KCfg>, dim3((unsigned)nblk), dim3(KCfg::NT), KCfg::SMEM_BYTES, st, h->dW,
-                               (int)h->Np, h->ntri, h->S, h->KS, h->dKslab);
-        r.flops = 2.0 * (double)h->ntri * 128.0 * 128.0 * (double)h->S * (double)h->KS;
+        hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), GemmNT<KCfg4>::SMEM_BYTES, st, h->dWt,
+                           h->Wld, h->ntri, h->S, h->KS, h->dKslab);
+        const double nT = (double)(h->Np / TILE_P);
+        // diagonal tiles: the wave that owns the upper 64 x 64 block issues no MFMA
+        r.flops = 2.0 * ((double)h->ntri - 0.25 * nT) * 128.0 * 128.0 * (double)h->S * (double)h->KS;
         r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
         r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
-        (void)hipEventRecord(r.e1, st);
+        ok(hipEventRecord(r.e1, st));
     };
     // record slots stay fixed (2 = J, 3 = K) whatever the launch order
     static const bool k_first = [] { const char *e = getenv("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
@@ -244,29 +256,28 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     if (overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk) {
         // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs
         if (!h->side) {
-            (void)hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
-            (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-            (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+            ok(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            ok(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            ok(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
-        (void)hipEventRecord(h->ev_fork, st);
-        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        ok(hipEventRecord(h->ev_fork, st));
+        ok(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         run_J(2, h->side);
         run_K(3);
-        (void)hipEventRecord(h->ev_join, h->side);
-        (void)hipStreamWaitEvent(st, h->ev_join, 0);
+        ok(hipEventRecord(h->ev_join, h->side));
+        ok(hipStreamWaitEvent(st, h->ev_join, 0));
     } else if (k_first) { run_K(3); run_J(2, st); } else { run_J(2, st); run_K(3); }
     k = 4;
     {
-        KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st);
+        KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st, ok);
         hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
-                           st, h->dJpart, h->SJ, h->dKslab, h->S, h->ntri, h->have_H ? h->dH : nullptr,
-                           (int)h->N, (int)h->Nk, (int)h->Np, dF);
+                           st, h->dJ, h->dCmap, h->dKslab, h->S, h->ntri, h->have_H ? h->dH : nullptr, (int)h->N, dF);
         r.alg_bytes = 8.0 * N * N * (h->have_H ? 2.0 : 1.0);
-        (void)hipEventRecord(r.e1, st);
+        ok(hipEventRecord(r.e1, st));
     }
-    (void)hipEventRecord(h->ev_end, st);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    ok(hipEventRecord(h->ev_end, st));
+    ok(hipGetLastError());
+    if (ok.first != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("Fock build enqueue: ") + hipGetErrorString(ok.first));
     h->pending = true;
     return JCDF_OK;
 }
@@ -278,62 +289,44 @@ double elapsed_s(hipEvent_t a, hipEvent_t b)
     return (double)ms * 1e-3;
 }
 
-int32_t ensure_stage(jcdf_handle *h, int64_t rows)
-{
-    if (h->stage_rows >= rows) return JCDF_OK;
-    dev_free(h, &h->dRaw, h->stage_rows * h->P);
-    dev_free(h, &h->dTint, roundup(h->stage_rows, KC) * h->Nk * h->Np);
-    h->stage_rows = 0;
-    int32_t rc = dev_alloc(h, &h->dRaw, rows * h->P, false);
-    if (rc) return rc;
-    rc = dev_alloc(h, &h->dTint, roundup(rows, KC) * h->Nk * h->Np, false);
-    if (rc) return rc;
-    h->stage_rows = rows;
-    return JCDF_OK;
-}
-
 void release_stage(jcdf_handle *h)
 {
-    dev_free(h, &h->dRaw, h->stage_rows * h->P);
-    dev_free(h, &h->dTint, roundup(h->stage_rows, KC) * h->Nk * h->Np);
-    h->stage_rows = 0;
+    dev_free(h, &h->dStage, h->stage_doubles);
+    h->stage_doubles = 0;
 }
 
-constexpr int64_t STAGE_ROWS = 256;
+constexpr int64_t STAGE_MAX_DOUBLES = (int64_t)1 << 28;      // 2 GiB of pushed three-centre rows on the device at a time
 
-// scatter `rows` aux rows (raw block on device, leading dim R) into dst [rows][Nk][Np]
-void launch_scatter(jcdf_handle *h, const double *raw, int64_t R, double *dst)
-{
-    dim3 grid((unsigned)((R + 31) / 32), (unsigned)((h->P + 31) / 32));
-    hipLaunchKernelGGL(k_scatter_T, grid, dim3(256), 0, h->stream, raw, R, h->P, h->dpq_p, h->dpq_q, (int)h->N,
-                       (int)h->Nk, (int)h->Np, dst);
-}
-
-// Accumulate B += Linv[q0:q1, s0:s1] * T for one block of rows.  `T` has leading
-// dimension ldT rows (column-major (ldT x P)); on_device selects the copy kind.
+// Accumulate Bp[:, r] += sum_{s in [s0,s1)} T[s][:] Linv[q0 + r][s].  `T` is the caller's block, column-major
+// ((s1-s0) x P); on_device selects the copy kind.  One metric-apply launch per sub-block of rows that fits the
+// staging buffer (all of them for the usual block sizes), so B is read and written once per push.
 int32_t push_block(jcdf_handle *h, int64_t s0, int64_t s1, const double *T, bool on_device)
 {
     const int64_t Rtot = s1 - s0;
-    const int64_t slab = h->Nk * h->Np;
-    for (int64_t a0 = 0; a0 < Rtot; a0 += STAGE_ROWS) {
-        const int64_t R = std::min(STAGE_ROWS, Rtot - a0);
-        int32_t rc = ensure_stage(h, STAGE_ROWS);
+    const int64_t Prows = roundup(h->P, MCfg::TM);
+    int64_t Rmax = std::max<int64_t>(KC, (STAGE_MAX_DOUBLES / Prows) / KC * KC);
+    Rmax = std::min(Rmax, roundup(Rtot, KC));
+    if (h->stage_doubles < Prows * Rmax) {
+        release_stage(h);
+        int32_t rc = dev_alloc(h, &h->dStage, Prows * Rmax, false);
         if (rc) return rc;
-        // sub-rows [a0, a0+R) of every column: 2-D copy, R*8 bytes wide, P columns
-        JCDF_HIP(h, hipMemcpy2DAsync(h->dRaw, (size_t)R * 8, T + a0, (size_t)Rtot * 8, (size_t)R * 8,
-                                     (size_t)h->P, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                     h->stream));
-        const int64_t Kpad = roundup(R, KC);
-        JCDF_HIP(h, hipMemsetAsync(h->dTint, 0, (size_t)(Kpad * slab) * 8, h->stream));
-        launch_scatter(h, h->dRaw, R, h->dTint);
-        const int n_xtiles = (int)(slab / MCfg::TN);
-        const int n_mt = (int)(roundup(h->Ql, MCfg::TM) / MCfg::TM);
+        h->stage_doubles = Prows * Rmax;
+    }
+    const int n_ctiles = (int)(Prows / MCfg::TM);
+    const int n_rt = (int)(roundup(h->Ql, MCfg::TN) / MCfg::TN);
+    for (int64_t a0 = 0; a0 < Rtot; a0 += Rmax) {
+        const int64_t R = std::min(Rmax, Rtot - a0), Rpad = roundup(R, KC);
+        // rows [a0, a0+R) of every column -> staging row c = [T[s0+a0 .. ][c], 0 ...] (leading dimension Rpad)
+        if (Rpad > R)
+            JCDF_HIP(h, hipMemset2DAsync(h->dStage + R, (size_t)Rpad * 8, 0, (size_t)(Rpad - R) * 8, (size_t)h->P, h->stream));
+        JCDF_HIP(h, hipMemcpy2DAsync(h->dStage, (size_t)Rpad * 8, T + a0, (size_t)Rtot * 8, (size_t)R * 8, (size_t)h->P,
+                                     on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         // L^-1 is lower triangular: rows of this shard above the block's first column get nothing
-        const int mt0 = (int)(std::max<int64_t>(0, s0 + a0 - h->q0) / MCfg::TM);
-        if (mt0 < n_mt)
-            hipLaunchKernelGGL(k_metric_apply, dim3((unsigned)(n_xtiles * (n_mt - mt0))), dim3(MCfg::NT),
-                               MCfg::SMEM_BYTES, h->stream, h->dLinvT + (s0 + a0) * h->ldl, h->ldl, h->dTint, slab,
-                               (int)Kpad, (int)h->Ql, n_xtiles, mt0, h->dB);
+        const int rt0 = (int)(std::max<int64_t>(0, s0 + a0 - h->q0) / MCfg::TN);
+        if (rt0 < n_rt)
+            hipLaunchKernelGGL(k_metric_apply, dim3((unsigned)((int64_t)n_ctiles * (n_rt - rt0))), dim3(MCfg::NT),
+                               GemmNT<MCfg>::SMEM_BYTES, h->stream, h->dStage, Rpad, h->P, h->dLinv + (s0 + a0), h->ldl,
+                               (int)(Rpad / KC), (int)h->Ql, n_ctiles, rt0, h->dB, h->ldq);
         if (!on_device) JCDF_HIP(h, hipStreamSynchronize(h->stream));   // host buffer may be reused by caller
     }
     hipError_t e = hipGetLastError();
@@ -342,6 +335,7 @@ int32_t push_block(jcdf_handle *h, int64_t s0, int64_t s1, const double *T, bool
 }
 
 // ---- device Cholesky + triangular inverse of the metric (jcdf_chol.hpp) ------------------------
+constexpr int CHOL_DIAG_LDS = 2 * CH_NB * (CH_NB + 1) * 8;
 struct CholBuffers {
     double *R = nullptr, *V = nullptr, *invU = nullptr, *UT = nullptr, *T = nullptr;
     int *err = nullptr;
@@ -377,14 +371,8 @@ hipError_t chol_inverse_device(hipStream_t st, const double *J, int64_t Q, CholB
     if (w.n_pad > Q)
         hipLaunchKernelGGL(k_chol_pad_diag, dim3((unsigned)((w.n_pad - Q + 127) / 128)), dim3(128), 0, st, w.R, w.ld,
                            (int)Q, (int)w.n_pad);
-    const int diag_lds = 2 * CH_NB * (CH_NB + 1) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds);
-        (void)hipFuncSetAttribute((const void *)k_chol_inv_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, C64Cfg::SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void *)k_chol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, C128Cfg::SMEM_BYTES);
-        attr_done = true;
-    }
+    CH(ensure_device_attributes());
+    const int diag_lds = CHOL_DIAG_LDS;
     // factor: R -> U (upper, row-major)
     for (int64_t b = 0; b < w.nblk; ++b) {
         const int64_t i0 = b * CH_NB, k0 = i0 + CH_NB, nk = w.n_pad - k0;
@@ -419,38 +407,50 @@ hipError_t chol_inverse_device(hipStream_t st, const double *J, int64_t Q, CholB
     return hipSuccess;
 }
 
-int32_t upload_linv(jcdf_handle *h, const double *Linv)
+// A new metric starts a new B: the next push zeroes it again (jcdf.h: "the first push zeroes B").
+int32_t alloc_linv(jcdf_handle *h)
 {
-    // LinvT[s][r] = Linv[(q0 + r) + Qtot * s]: column s of Linv restricted to the shard's rows
-    h->ldl = roundup(h->Ql, MCfg::TM);
-    h->linv_rows = h->Qtot + 2 * KC;
-    if (!h->dLinvT) {
-        int32_t rc = dev_alloc(h, &h->dLinvT, h->linv_rows * h->ldl, true);
+    h->ldl = roundup(h->Qtot, KC) + KC;                 // a pushed block's zero-padded tail may reach KC-1 columns past Qtot
+    h->linv_rows = roundup(h->Ql, MCfg::TN);
+    if (!h->dLinv) {
+        int32_t rc = dev_alloc(h, &h->dLinv, h->linv_rows * h->ldl, true);
         if (rc) return rc;
     } else {
-        JCDF_HIP(h, hipMemsetAsync(h->dLinvT, 0, (size_t)(h->linv_rows * h->ldl) * 8, h->stream));
+        JCDF_HIP(h, hipMemsetAsync(h->dLinv, 0, (size_t)(h->linv_rows * h->ldl) * 8, h->stream));
     }
-    JCDF_HIP(h, hipMemcpy2DAsync(h->dLinvT, (size_t)h->ldl * 8, Linv + h->q0, (size_t)h->Qtot * 8,
-                                 (size_t)h->Ql * 8, (size_t)h->Qtot, hipMemcpyHostToDevice, h->stream));
+    h->pushed_any = h->have_B = false;
+    return JCDF_OK;
+}
+
+int32_t upload_linv(jcdf_handle *h, const double *Linv)
+{
+    // dLinv[r][s] = Linv[(q0 + r) + Qtot * s]: rows of this shard, s contiguous
+    int32_t rc = alloc_linv(h);
+    if (rc) return rc;
+    std::vector<double> rows;
+    try {
+        rows.assign((size_t)(h->Ql * h->Qtot), 0.0);
+    } catch (...) {
+        return fail(h, JCDF_ERR_ALLOC, "jcdf_set_metric: out of host memory");
+    }
+    for (int64_t s = 0; s < h->Qtot; ++s)
+        for (int64_t r = std::max<int64_t>(0, s - h->q0); r < h->Ql; ++r)      // lower triangular: q0 + r >= s
+            rows[(size_t)(r * h->Qtot + s)] = Linv[(h->q0 + r) + h->Qtot * s];
+    JCDF_HIP(h, hipMemcpy2DAsync(h->dLinv, (size_t)h->ldl * 8, rows.data(), (size_t)h->Qtot * 8, (size_t)h->Qtot * 8,
+                                 (size_t)h->Ql, hipMemcpyHostToDevice, h->stream));
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_metric = true;
     return JCDF_OK;
 }
 
-
-// LinvT[s][r] = V[s][q0 + r] straight from the device factorisation
+// dLinv[r][s] = V[s][q0 + r] straight from the device factorisation (V = L^-T, row-major upper)
 int32_t upload_linv_from_device(jcdf_handle *h, const CholBuffers &w)
 {
-    h->ldl = roundup(h->Ql, MCfg::TM);
-    h->linv_rows = h->Qtot + 2 * KC;
-    if (!h->dLinvT) {
-        int32_t rc = dev_alloc(h, &h->dLinvT, h->linv_rows * h->ldl, true);
-        if (rc) return rc;
-    } else {
-        JCDF_HIP(h, hipMemsetAsync(h->dLinvT, 0, (size_t)(h->linv_rows * h->ldl) * 8, h->stream));
-    }
-    JCDF_HIP(h, hipMemcpy2DAsync(h->dLinvT, (size_t)h->ldl * 8, w.V + h->q0, (size_t)w.ld * 8, (size_t)h->Ql * 8,
-                                 (size_t)h->Qtot, hipMemcpyDeviceToDevice, h->stream));
+    int32_t rc = alloc_linv(h);
+    if (rc) return rc;
+    dim3 grid((unsigned)((h->Ql + 31) / 32), (unsigned)((h->Qtot + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, w.V, w.ld, h->q0, h->Ql, h->Qtot, h->dLinv, h->ldl);
+    JCDF_HIP(h, hipGetLastError());
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_metric = true;
     return JCDF_OK;
@@ -551,6 +551,43 @@ DcWork dc_carve(char *base, int64_t n, const DcPlan *plan)
     return wk;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set for every fixed-size kernel of the
+// library each time a handle is created on a device (and by the stand-alone entry points on their current device).
+hipError_t set_device_kernel_attributes()
+{
+    hipError_t first = hipSuccess;
+    auto set = [&](const void *f, int bytes) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (first == hipSuccess && e != hipSuccess) first = e;
+    };
+    set((const void *)k_exchange_K<KCfg4>, GemmNT<KCfg4>::SMEM_BYTES);
+    set((const void *)k_metric_apply, GemmNT<MCfg>::SMEM_BYTES);
+    set((const void *)k_coulomb_J, 150 * 1024);
+    set((const void *)k_chol_diag, CHOL_DIAG_LDS);
+    set((const void *)k_chol_inv_gemm, C64Cfg::SMEM_BYTES);
+    set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
+    set((const void *)k_chol_small, 128 * 129 * 8);
+    set((const void *)k_trsm_small, (128 * 129 + 128 * 17) * 8);
+    set((const void *)k_dc_update_mfma, DcCfg::SMEM_BYTES);
+    set((const void *)k_dc_prepare, 64 * 1024);
+    return first;
+}
+
+// once per device of this process (jcdf_create and the stand-alone entry points, which run on the current device)
+hipError_t ensure_device_attributes()
+{
+    static std::mutex mtx;
+    static std::vector<int> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (std::find(done.begin(), done.end(), dev) != done.end()) return hipSuccess;
+    e = set_device_kernel_attributes();
+    if (e == hipSuccess) done.push_back(dev);
+    return e;
+}
+
 }  // namespace
 
 // ============================================================================
@@ -596,16 +633,13 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
     }
     h->stream = h->own_stream;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    (void)hipEventCreate(&h->ev_begin);
-    (void)hipEventCreate(&h->ev_end);
-    (void)hipEventCreate(&h->ev_h2d);
-    (void)hipEventCreate(&h->ev_d2h);
-    (void)hipFuncSetAttribute((const void *)k_exchange_K<KCfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              KCfg::SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void *)k_exchange_K<KCfg4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              KCfg4::SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void *)k_metric_apply, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MCfg::SMEM_BYTES);
+    if ((e = hipEventCreate(&h->ev_begin)) != hipSuccess || (e = hipEventCreate(&h->ev_end)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev_h2d)) != hipSuccess || (e = hipEventCreate(&h->ev_d2h)) != hipSuccess ||
+        (e = ensure_device_attributes()) != hipSuccess) {
+        g_create_error = std::string("jcdf_create: ") + hipGetErrorString(e);
+        jcdf_destroy(h);
+        return JCDF_ERR_HIP;
+    }
     *out = h;
     return JCDF_OK;
 }
@@ -668,10 +702,14 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
 
     h->N = N; h->Qtot = Q_total; h->q0 = q0; h->q1 = q1; h->Ql = q1 - q0; h->o = n_occ; h->P = P;
     h->dense_map = (pq_p == nullptr);
-    h->kept_tile_fraction = 1.0;
-    h->Nk = roundup(N, KC);
     h->Np = roundup(N, TILE_P);
-    h->n_ntiles = (int)(h->Np / TILE_P);
+    // row length of the packed tensor; a row stride that is a multiple of 4 KB would put the 16 rows of a stage on the
+    // same HBM channel phase
+    h->ldq = roundup(h->Ql, KC);
+    if (h->ldq % 512 == 0) h->ldq += KC;
+    h->n_qt = (int)((h->ldq + TILE_Q - 1) / TILE_Q);
+    h->vld = h->n_qt * TILE_Q;
+    if ((size_t)h->ldq * 8 > 150 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux shard too long for the Coulomb kernel's LDS copy of V (use more shards)");
     // orbital (M) tiling of the W kernel: up to 128 orbitals -> one 4-wave workgroup holds them all;
     // more -> 8-wave workgroups of up to 256 orbitals (two wave rows share the staged B tile)
     if (n_occ <= 128 || getenv("JCDF_W_NO_WVM2")) {
@@ -685,12 +723,75 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         if (h->WMw < 5) h->WMw = 5;
     }
     h->opad = h->n_mtiles * h->WVMw * h->WMw * 16;
-    h->nvp = h->n_ntiles * h->n_mtiles;
-    launch_W(h, nullptr, true);
+    JCDF_HIP(h, launch_W(h, nullptr, true));
+
+    // ---- stage table of the W kernel + the Coulomb kernel's row list, from the packed pair list ----------------
+    // For every p the kept (c, q) in packed order, in stages of KC slots; slots past K_p point at the zero row of C
+    // (and at any valid row of B).  The pattern does not depend on the aux index, so this is built once.
+    std::vector<int> stg_c, stg_q, stg_p, wchunk, jrow, cmap;
+    try {
+        std::vector<int64_t> pstart((size_t)N + 1, 0);
+        std::vector<int> order;                       // packed indices grouped by p (stable); empty: already grouped
+        if (pq_p) {
+            bool grouped = true;
+            for (int64_t c = 0; c < P; ++c) {
+                pstart[(size_t)pq_p[c] + 1]++;
+                if (c && pq_p[c] < pq_p[c - 1]) grouped = false;
+            }
+            for (int64_t p = 0; p < N; ++p) pstart[(size_t)p + 1] += pstart[(size_t)p];
+            if (!grouped) {
+                order.resize((size_t)P);
+                std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+                for (int64_t c = 0; c < P; ++c) order[(size_t)fill[(size_t)pq_p[c]]++] = (int)c;
+            }
+        } else {
+            for (int64_t p = 0; p <= N; ++p) pstart[(size_t)p] = p * N;
+        }
+        cmap.assign((size_t)(N * N), -1);
+        jrow.reserve((size_t)(P / 2 + N));
+        int64_t total_stages = 0;
+        for (int64_t p = 0; p < N; ++p) total_stages += std::max<int64_t>(1, (pstart[(size_t)p + 1] - pstart[(size_t)p] + KC - 1) / KC);
+        stg_c.reserve((size_t)total_stages * KC);
+        stg_q.reserve((size_t)total_stages * KC);
+        stg_p.reserve((size_t)total_stages);
+        // ~16 workgroups per resident slot (2 per CU), at least one p and >= 16 stages each
+        const int64_t tiles = total_stages * h->n_qt * h->n_mtiles;
+        int64_t target = std::min<int64_t>(256, std::max<int64_t>(16, tiles / (16 * 2 * (int64_t)h->num_cu)));
+        if (const char *e = getenv("JCDF_W_CHUNK_STAGES")) target = std::max(1, atoi(e));
+        wchunk.push_back(0);
+        int64_t in_chunk = 0;
+        for (int64_t p = 0; p < N; ++p) {
+            const int64_t k0 = pstart[(size_t)p], Kp = pstart[(size_t)p + 1] - k0;
+            const int64_t ns = std::max<int64_t>(1, (Kp + KC - 1) / KC);
+            int last_c = 0;
+            for (int64_t j = 0; j < ns * KC; ++j) {
+                if (j < Kp) {
+                    const int64_t c = order.empty() ? k0 + j : order[(size_t)(k0 + j)];
+                    const int64_t q = pq_q ? pq_q[c] : j;
+                    last_c = (int)c;
+                    stg_c.push_back((int)c);
+                    stg_q.push_back((int)q);
+                    if (q >= p) { cmap[(size_t)(q + N * p)] = (int)jrow.size(); jrow.push_back((int)c); }
+                } else {
+                    stg_c.push_back(last_c);
+                    stg_q.push_back((int)N);
+                }
+            }
+            for (int64_t t = 0; t < ns; ++t) stg_p.push_back(t == ns - 1 ? (int)p : -1);
+            in_chunk += ns;
+            if (in_chunk >= target || p == N - 1) { wchunk.push_back((int)stg_p.size()); in_chunk = 0; }
+        }
+    } catch (...) {
+        return fail(h, JCDF_ERR_ALLOC, "jcdf_configure: out of host memory for the stage table");
+    }
+    h->n_stages = (int)stg_p.size();
+    h->n_chunks = (int)wchunk.size() - 1;
+    h->Plow = (int64_t)jrow.size();
+
     // K: lower block-triangle of 128x128 tiles, split-K so that one wave of workgroups fills the chip
-    const int nT = h->n_ntiles;
+    const int nT = (int)(h->Np / TILE_P);
     h->ntri = nT * (nT + 1) / 2;
-    const int64_t Ktot = h->Ql * h->o;
+    const int64_t Ktot = h->o * h->ldq;
     // Split-K: all tiles of one k-slice run on one XCD (they share W rows through that L2), so the slice count is a
     // multiple of 8: m slices per XCD.  Measured (tools/prof_fock.py, JCDF_K_SLICES_PER_XCD): when the lower triangle has
     // at most one tile per CU of an XCD, the best m is the largest for which all ntri * m workgroups are resident at once
@@ -722,62 +823,28 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     if (S > max_chunks) S = std::max<int64_t>(1, max_chunks);
     h->KS = (int)roundup((Ktot + S - 1) / S, KC);
     h->S = (int)((Ktot + h->KS - 1) / h->KS);
-    h->Wrows = (int64_t)h->S * h->KS;
-    // J: slices over the aux index so that ~8 blocks per CU are in flight
-    const int64_t jrow_blocks = (N + J_ROWS - 1) / J_ROWS;
-    int64_t SJ = std::max<int64_t>(1, (8 * (int64_t)h->num_cu + jrow_blocks - 1) / jrow_blocks);
-    SJ = std::min<int64_t>(SJ, std::max<int64_t>(1, h->Ql / 16));
-    h->QS = (int)((h->Ql + SJ - 1) / SJ);
-    h->SJ = (int)((h->Ql + h->QS - 1) / h->QS);
-    if ((size_t)h->QS * 8 > 48 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux slice too long");
+    h->Wld = (int64_t)h->S * h->KS;
 
     int32_t rc;
-    if ((rc = dev_alloc(h, &h->dB, h->Ql * h->Nk * h->Np, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dCpad, h->Np * h->opad, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dCperm, h->Np * h->opad, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dW, h->Wrows * h->Np, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dVpart, h->Ql * h->nvp, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dV, h->Ql, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dJpart, (int64_t)h->SJ * h->Nk * h->Np, true))) return rc;
+    // KC rows + one aux tile of slack: a partial last aux tile reads past the end of its rows
+    if ((rc = dev_alloc(h, &h->dB, (h->P + KC) * h->ldq + 2 * TILE_Q, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dCpad, (h->Np + KC) * h->opad, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dCv, N * h->opad, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dWt, h->Np * h->Wld, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dVpart, (int64_t)h->n_chunks * h->n_mtiles * h->vld, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dV, h->ldq, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dJ, h->Plow, true))) return rc;
     if ((rc = dev_alloc(h, &h->dKslab, (int64_t)h->S * h->ntri * 128 * 128, true))) return rc;
     if ((rc = dev_alloc(h, &h->dH, N * N, true))) return rc;
     if ((rc = dev_alloc(h, &h->dF, N * N, true))) return rc;
     if ((rc = dev_alloc(h, &h->dC, N * n_occ, true))) return rc;
-    if (pq_p) {
-        if ((rc = dev_alloc(h, &h->dpq_p, P, false))) return rc;
-        if ((rc = dev_alloc(h, &h->dpq_q, P, false))) return rc;
-        JCDF_HIP(h, hipMemcpyAsync(h->dpq_p, pq_p, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
-        JCDF_HIP(h, hipMemcpyAsync(h->dpq_q, pq_q, (size_t)P * 8, hipMemcpyHostToDevice, h->stream));
-        // Block-sparse metadata from the packed (Schwarz-screened) pair list.  The pattern is the same
-        // for every aux index, so it is built once: for each 128-column tile the list of 16-row k
-        // stages that contain a kept pair (W kernel), and for each 8-row block the set of non-empty
-        // 128-column tiles (J kernel).  Everything else in B is exactly zero and is never read.
-        if (h->n_ntiles <= 64) {
-            const int nkc = (int)(h->Nk / KC), nrb = (int)((N + J_ROWS - 1) / J_ROWS);
-            std::vector<uint8_t> tile((size_t)nkc * h->n_ntiles, 0);
-            std::vector<unsigned long long> jm((size_t)nrb, 0ULL);
-            for (int64_t c = 0; c < P; ++c) {
-                const int64_t p = pq_p[c], q = pq_q[c];
-                tile[(size_t)(q / KC) * h->n_ntiles + (size_t)(p / TILE_P)] = 1;
-                if (p <= q) jm[(size_t)(q / J_ROWS)] |= 1ULL << (p / TILE_P);
-            }
-            std::vector<int> kptr((size_t)h->n_ntiles + 1, 0), klist;
-            for (int t = 0; t < h->n_ntiles; ++t) {
-                for (int kc = 0; kc < nkc; ++kc)
-                    if (tile[(size_t)kc * h->n_ntiles + t]) klist.push_back(kc);
-                kptr[(size_t)t + 1] = (int)klist.size();
-            }
-            h->kept_tile_fraction = (double)klist.size() / ((double)nkc * h->n_ntiles);
-            if ((rc = dev_alloc(h, &h->dWkptr, (int64_t)kptr.size(), false))) return rc;
-            if ((rc = dev_alloc(h, &h->dWklist, (int64_t)std::max<size_t>(klist.size(), 1), false))) return rc;
-            if ((rc = dev_alloc(h, &h->dJmask, (int64_t)jm.size(), false))) return rc;
-            JCDF_HIP(h, hipMemcpy(h->dWkptr, kptr.data(), kptr.size() * sizeof(int), hipMemcpyHostToDevice));
-            if (!klist.empty())
-                JCDF_HIP(h, hipMemcpy(h->dWklist, klist.data(), klist.size() * sizeof(int), hipMemcpyHostToDevice));
-            JCDF_HIP(h, hipMemcpy(h->dJmask, jm.data(), jm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-        }
-    }
-    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_upload(h, &h->dWchunk, wchunk))) return rc;
+    if ((rc = dev_upload(h, &h->dStgC, stg_c))) return rc;
+    if ((rc = dev_upload(h, &h->dStgQ, stg_q))) return rc;
+    if ((rc = dev_upload(h, &h->dStgP, stg_p))) return rc;
+    if ((rc = dev_upload(h, &h->dJrow, jrow))) return rc;
+    if ((rc = dev_upload(h, &h->dCmap, cmap))) return rc;
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));       // the host vectors above go out of scope
     h->configured = true;
     return JCDF_OK;
 }
@@ -841,7 +908,7 @@ int32_t jcdf_push_three_center(jcdf_handle *h, int64_t s0, int64_t s1, const dou
     if (!T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center: bad row range");
     JCDF_HIP(h, hipSetDevice(h->device));
     if (!h->pushed_any) {
-        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * h->Nk * h->Np) * 8, h->stream));
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 2 * TILE_Q) * 8, h->stream));
         h->pushed_any = true;
     }
     if (s0 >= h->q1) return JCDF_OK;                 // Linv[q0:q1, s0:s1] == 0 (lower triangular)
@@ -858,7 +925,7 @@ int32_t jcdf_push_three_center_device(jcdf_handle *h, int64_t s0, int64_t s1, co
     if (!d_T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center_device: bad row range");
     JCDF_HIP(h, hipSetDevice(h->device));
     if (!h->pushed_any) {
-        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * h->Nk * h->Np) * 8, h->stream));
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 2 * TILE_Q) * 8, h->stream));
         h->pushed_any = true;
     }
     if (s0 >= h->q1) return JCDF_OK;
@@ -874,18 +941,10 @@ int32_t jcdf_set_B(jcdf_handle *h, const double *B)
     if (!h) return JCDF_ERR_INVALID;
     if (!h->configured || !B) return fail(h, JCDF_ERR_INVALID, "jcdf_set_B: configure first / NULL");
     JCDF_HIP(h, hipSetDevice(h->device));
-    const int64_t slab = h->Nk * h->Np;
-    JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)(h->Ql * slab) * 8, h->stream));
-    for (int64_t a0 = 0; a0 < h->Ql; a0 += STAGE_ROWS) {
-        const int64_t R = std::min(STAGE_ROWS, h->Ql - a0);
-        int32_t rc = ensure_stage(h, STAGE_ROWS);
-        if (rc) return rc;
-        JCDF_HIP(h, hipMemcpy2DAsync(h->dRaw, (size_t)R * 8, B + a0, (size_t)h->Ql * 8, (size_t)R * 8, (size_t)h->P,
-                                     hipMemcpyHostToDevice, h->stream));
-        launch_scatter(h, h->dRaw, R, h->dB + a0 * slab);
-        JCDF_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    release_stage(h);
+    // the device layout IS the reference's (Q_d, P) column-major, only the leading dimension is padded
+    JCDF_HIP(h, hipMemcpy2DAsync(h->dB, (size_t)h->ldq * 8, B, (size_t)h->Ql * 8, (size_t)h->Ql * 8, (size_t)h->P,
+                                 hipMemcpyHostToDevice, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_B = true;
     h->pushed_any = true;
     return JCDF_OK;
@@ -896,19 +955,9 @@ int32_t jcdf_get_B(jcdf_handle *h, double *B_out)
     if (!h) return JCDF_ERR_INVALID;
     if (!h->configured || !h->have_B || !B_out) return fail(h, JCDF_ERR_INVALID, "jcdf_get_B: no B yet / NULL");
     JCDF_HIP(h, hipSetDevice(h->device));
-    const int64_t slab = h->Nk * h->Np;
-    for (int64_t a0 = 0; a0 < h->Ql; a0 += STAGE_ROWS) {
-        const int64_t R = std::min(STAGE_ROWS, h->Ql - a0);
-        int32_t rc = ensure_stage(h, STAGE_ROWS);
-        if (rc) return rc;
-        dim3 grid((unsigned)((R + 31) / 32), (unsigned)((h->P + 31) / 32));
-        hipLaunchKernelGGL(k_gather_T, grid, dim3(256), 0, h->stream, h->dB + a0 * slab, R, h->P, h->dpq_p,
-                           h->dpq_q, (int)h->N, (int)h->Nk, (int)h->Np, h->dRaw);
-        JCDF_HIP(h, hipMemcpy2DAsync(B_out + a0, (size_t)h->Ql * 8, h->dRaw, (size_t)R * 8, (size_t)R * 8,
-                                     (size_t)h->P, hipMemcpyDeviceToHost, h->stream));
-        JCDF_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    release_stage(h);
+    JCDF_HIP(h, hipMemcpy2DAsync(B_out, (size_t)h->Ql * 8, h->dB, (size_t)h->ldq * 8, (size_t)h->Ql * 8, (size_t)h->P,
+                                 hipMemcpyDeviceToHost, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
     return JCDF_OK;
 }
 
@@ -930,7 +979,7 @@ int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_
     if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device: B not set");
     if (!d_C_occ || !d_F) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device: NULL pointer");
     JCDF_HIP(h, hipSetDevice(h->device));
-    if (h->stage_rows) release_stage(h);
+    if (h->stage_doubles) release_stage(h);
     h->timed_host_copy = false;
     return enqueue_fock(h, d_C_occ, d_F, stream ? (hipStream_t)stream : h->stream);
 }
@@ -973,8 +1022,8 @@ int32_t jcdf_fock_build_begin(jcdf_handle *h, const double *C_occ)
     if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_begin: B not set");
     if (!C_occ) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_begin: NULL pointer");
     JCDF_HIP(h, hipSetDevice(h->device));
-    if (h->stage_rows) release_stage(h);
-    (void)hipEventRecord(h->ev_h2d, h->stream);
+    if (h->stage_doubles) release_stage(h);
+    JCDF_HIP(h, hipEventRecord(h->ev_h2d, h->stream));
     // pageable host memory: the copy has left the caller's buffer when this returns
     JCDF_HIP(h, hipMemcpyAsync(h->dC, C_occ, (size_t)(h->N * h->o) * 8, hipMemcpyHostToDevice, h->stream));
     return enqueue_fock(h, h->dC, h->dF, h->stream);
@@ -986,7 +1035,7 @@ int32_t jcdf_fock_build_finish(jcdf_handle *h, double *F_out, jcdf_timings *t)
     if (!h->configured || !F_out) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_finish: not configured / NULL");
     JCDF_HIP(h, hipSetDevice(h->device));
     JCDF_HIP(h, hipMemcpyAsync(F_out, h->dF, (size_t)(h->N * h->N) * 8, hipMemcpyDeviceToHost, h->stream));
-    (void)hipEventRecord(h->ev_d2h, h->stream);
+    JCDF_HIP(h, hipEventRecord(h->ev_d2h, h->stream));
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->timed_host_copy = true;
     return jcdf_synchronize(h, t);
@@ -1020,8 +1069,8 @@ int32_t jcdf_get_W(jcdf_handle *h, double *W_out)
     double *tmp = nullptr;
     int32_t rc = dev_alloc(h, &tmp, total, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_export_W, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->dW,
-                       (int)h->Ql, (int)h->o, (int)h->N, (int)h->Np, tmp);
+    hipLaunchKernelGGL(k_export_W, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->dWt, h->Wld, h->ldq,
+                       (int)h->Ql, (int)h->o, (int)h->N, tmp);
     hipError_t e = hipMemcpyAsync(W_out, tmp, (size_t)total * 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     dev_free(h, &tmp, total);
@@ -1144,12 +1193,7 @@ int32_t jcdf_orthonormalise_rows_device(void *stream, int64_t o, int64_t n, cons
                                         double *d_L, double *d_pivot)
 {
     if (o < 1 || o > 128 || n < 1 || !d_G || !d_Y || !d_Z || !d_L || !d_pivot) return JCDF_ERR_INVALID;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
-        (void)hipFuncSetAttribute((const void *)k_trsm_small, hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 129 + 128 * 17) * 8);
-        attr_done = true;
-    }
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), (size_t)o * (o + 1) * 8, st, d_G, o, (int)o, d_L, o, d_pivot);
     hipLaunchKernelGGL(k_trsm_small, dim3((unsigned)((n + 15) / 16)), dim3(256), ((size_t)o * (o + 1) + (size_t)o * 17) * 8, st, d_L, o,
@@ -1229,12 +1273,7 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
     DcWork wk = dc_carve((char *)d_work, n, plan);
     if (work_bytes < wk.bytes) return JCDF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_dc_update_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, DcCfg::SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void *)k_dc_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_done = true;
-    }
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
     const int L = (int)plan->levels.size();
     // ping-pong so that the last level writes into the caller's buffers: eigenvalues end in d_D, vectors in d_Z
     double *Za = (L % 2 == 0) ? d_Z : wk.Zb, *Zn = (L % 2 == 0) ? wk.Zb : d_Z;

@@ -175,6 +175,105 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
     }
 }
 
+// ---------------------------------------------------------------------------
+// "NT" variant: both operands are stored with the CONTRACTION index contiguous,
+//
+//   acc[m][n] += sum_k A[m][k] * B[n][k]
+//
+//   K pass  : A = Wt [p ][(i,Q)]     B = Wt   [p'][(i,Q)]   (SYRK over the packed exchange intermediate)
+//   metric  : A = T  [c ][s]         B = Linv [r ][s]       (B = L^-1 T in the reference's (Q_d, P) layout)
+//
+// A stage is TM (resp. TN) rows x KC contiguous doubles (one 128-B line per row for KC = 16);
+// every thread moves 16 B along k.  The LDS image keeps the global orientation, rows padded to
+// KC + 2 doubles: the 32 lanes of a ds_read_b64 group (16 rows x 2 k) then hit 32 different
+// bank pairs ((row * (KC+2) + k) mod 32 is a bijection for KC = 16 and 32), stores are 16-B aligned.
+template <class Cfg>
+struct GemmNT {
+    static constexpr int KC = Cfg::KC, TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
+    static constexpr int LDK = KC + 2;
+    static constexpr int STAGE_DOUBLES = (TM + TN) * LDK;
+    static constexpr int SMEM_BYTES = 2 * STAGE_DOUBLES * 8;
+    static constexpr int A_VEC = TM * KC / 2, B_VEC = TN * KC / 2;
+    static constexpr int A_PER_THREAD = (A_VEC + NT - 1) / NT, B_PER_THREAD = (B_VEC + NT - 1) / NT;
+    static_assert(A_VEC % NT == 0 && B_VEC % NT == 0, "tile does not divide over the threads");
+};
+
+// Ag -> A[m0][k0], Bg -> B[n0][k0]; lda/ldb = row strides in doubles (even); nchunks = K / KC.
+// STREAM_A: the A operand is read once from HBM by the whole grid (non-temporal loads).
+// SAME: the A and B tiles are the same rows (diagonal tile of a SYRK): B is neither loaded nor staged.
+template <class Cfg, bool STREAM_A = false>
+__device__ __forceinline__ void gemm_nt_core(const double *__restrict__ Ag, int64_t lda,
+                                             const double *__restrict__ Bg, int64_t ldb, int nchunks,
+                                             double4_t (&acc)[Cfg::WM][Cfg::WN], double *smem, bool same = false)
+{
+    using G = GemmNT<Cfg>;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, KC = Cfg::KC, NT = Cfg::NT, LDK = G::LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    double2_t ra[G::A_PER_THREAD], rb[G::B_PER_THREAD];
+    auto load_stage = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < G::A_PER_THREAD; ++i) {
+            const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
+            const double2_t *src = reinterpret_cast<const double2_t *>(Ag + (int64_t)r * lda + (int64_t)chunk * KC + 2 * c);
+            ra[i] = STREAM_A ? __builtin_nontemporal_load(src) : *src;
+        }
+        if (!same)
+#pragma unroll
+            for (int i = 0; i < G::B_PER_THREAD; ++i) {
+                const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
+                rb[i] = *reinterpret_cast<const double2_t *>(Bg + (int64_t)r * ldb + (int64_t)chunk * KC + 2 * c);
+            }
+    };
+    auto store_stage = [&](int buf) {
+        double *As = smem + buf * G::STAGE_DOUBLES;
+        double *Bs = As + Cfg::TM * LDK;
+#pragma unroll
+        for (int i = 0; i < G::A_PER_THREAD; ++i) {
+            const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
+            *reinterpret_cast<double2_t *>(As + r * LDK + 2 * c) = ra[i];
+        }
+        if (!same)
+#pragma unroll
+            for (int i = 0; i < G::B_PER_THREAD; ++i) {
+                const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
+                *reinterpret_cast<double2_t *>(Bs + r * LDK + 2 * c) = rb[i];
+            }
+    };
+    auto compute_stage = [&](int buf) {
+        const double *As = smem + buf * G::STAGE_DOUBLES + (wm * (WM * 16) + lr) * LDK + lk;
+        const double *Bs = smem + buf * G::STAGE_DOUBLES + (same ? 0 : Cfg::TM * LDK) + (wn * (WN * 16) + lr) * LDK + lk;
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double a[WM], b[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) a[m] = As[m * 16 * LDK + ks * 4];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) b[n] = Bs[n * 16 * LDK + ks * 4];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nchunks; ++t) {
+        const bool more = (t + 1 < nchunks);
+        if (more) load_stage(t + 1);
+        compute_stage(cur);
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // Element coordinates of acc[m][n][j] inside the workgroup tile.
 template <class Cfg>
 __device__ __forceinline__ int tile_row(int m, int j)
