@@ -201,10 +201,15 @@ struct GemmNT {
 // Ag -> A[m0][k0], Bg -> B[n0][k0]; lda/ldb = row strides in doubles (even); nchunks = K / KC.
 // STREAM_A: the A operand is read once from HBM by the whole grid (non-temporal loads).
 // SAME: the A and B tiles are the same rows (diagonal tile of a SYRK): B is neither loaded nor staged.
-template <class Cfg, bool STREAM_A = false>
+// BLOCKED: the operands are stored in blocks of (tile rows x KC) (chunk t of a tile is one contiguous block, lda/ldb = KC):
+// consecutive chunks are TM*KC (resp. TN*KC) doubles apart.
+// mfma_on = false: this wave issues no MFMA (its accumulators are not needed: upper block of a diagonal SYRK tile);
+// it still loads, stages and meets every barrier.
+template <class Cfg, bool STREAM_A = false, bool BLOCKED = false>
 __device__ __forceinline__ void gemm_nt_core(const double *__restrict__ Ag, int64_t lda,
                                              const double *__restrict__ Bg, int64_t ldb, int nchunks,
-                                             double4_t (&acc)[Cfg::WM][Cfg::WN], double *smem, bool same = false)
+                                             double4_t (&acc)[Cfg::WM][Cfg::WN], double *smem, bool same = false,
+                                             bool mfma_on = true)
 {
     using G = GemmNT<Cfg>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, KC = Cfg::KC, NT = Cfg::NT, LDK = G::LDK;
@@ -217,14 +222,14 @@ __device__ __forceinline__ void gemm_nt_core(const double *__restrict__ Ag, int6
 #pragma unroll
         for (int i = 0; i < G::A_PER_THREAD; ++i) {
             const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
-            const double2_t *src = reinterpret_cast<const double2_t *>(Ag + (int64_t)r * lda + (int64_t)chunk * KC + 2 * c);
+            const double2_t *src = reinterpret_cast<const double2_t *>(Ag + (int64_t)r * lda + (int64_t)chunk * (BLOCKED ? Cfg::TM * KC : KC) + 2 * c);
             ra[i] = STREAM_A ? __builtin_nontemporal_load(src) : *src;
         }
         if (!same)
 #pragma unroll
             for (int i = 0; i < G::B_PER_THREAD; ++i) {
                 const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
-                rb[i] = *reinterpret_cast<const double2_t *>(Bg + (int64_t)r * ldb + (int64_t)chunk * KC + 2 * c);
+                rb[i] = *reinterpret_cast<const double2_t *>(Bg + (int64_t)r * ldb + (int64_t)chunk * (BLOCKED ? Cfg::TN * KC : KC) + 2 * c);
             }
     };
     auto store_stage = [&](int buf) {
@@ -243,6 +248,7 @@ __device__ __forceinline__ void gemm_nt_core(const double *__restrict__ Ag, int6
             }
     };
     auto compute_stage = [&](int buf) {
+        if (!mfma_on) return;
         const double *As = smem + buf * G::STAGE_DOUBLES + (wm * (WM * 16) + lr) * LDK + lk;
         const double *Bs = smem + buf * G::STAGE_DOUBLES + (same ? 0 : Cfg::TM * LDK) + (wn * (WN * 16) + lr) * LDK + lk;
 #pragma unroll

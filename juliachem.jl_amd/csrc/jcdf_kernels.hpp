@@ -9,9 +9,11 @@
 //                             "zero row" the padding slots of a stage point at).
 //   Cv    [N][n_mt][WVM][4][4 WM]   the same numbers permuted into the fp64 MFMA accumulator layout for
 //                             the fused-V epilogue of the W kernel.
-//   Wt    [Np][Wld]           exchange intermediate Wt[p][i*ldq + Q] (the reference's W (Q_d, o, N),
-//                             GPUDF.jl:140, with the orbital index moved outside the aux index);
-//                             Wld = S*KS >= o*ldq, the tail and rows >= N are 0.
+//   Wb    [Np/128][Wld/16][128][16]   exchange intermediate W[p][k], k = i*ldq + Q (the reference's W (Q_d, o, N),
+//                             GPUDF.jl:140, with the orbital index moved outside the aux index), blocked so that
+//                             the 128 p of a K-kernel tile x 16 consecutive k are one contiguous 16 KB block:
+//                             element (p, k) at ((p/128 * Wld/16 + k/16) * 128 + p%128) * 16 + k%16.
+//                             Wld = S*KS >= o*ldq; the k tail and the rows p >= N are 0.
 //   vpart [n_chunks*n_mt][vld]  per-workgroup-chunk partial sums of V[Q] (deterministic order).
 //   J     [Plow]              Coulomb matrix on the kept pairs with q >= p.
 //   Kslab [S][ntri][128][128] split-K partial exchange tiles (lower block-triangle).
@@ -96,35 +98,42 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
     const double *Ag = Cpad + mt * TM;
     const double *Bg = Bp + (int64_t)qt * TILE_Q + 2 * lane;
 
-    // this wave's rows of a stage: A slot s = wave + i NW -> row s / AH, half s % AH; B row wave + i NW
-    double2_t ra0[A_PER], rb0[B_PER], ra1[A_PER], rb1[B_PER];
-    int iq[A_PER], ic[B_PER];                        // wave-uniform gather indices of the NEXT stage to load
-    auto load_idx = [&](int t) {
-        const int *sq = stg_q + (int64_t)(t0 + t) * 16, *sc = stg_c + (int64_t)(t0 + t) * 16;
+    // this wave's rows of a stage: A slot s = wave + i NW -> row s / AH, half s % AH; B row wave + i NW.
+    // B (HBM, read once) travels through two register sets, two phases ahead of its use; A (the C rows, L2 resident)
+    // through one set, one phase ahead — with two sets for both the 96..128-orbital forms spill.
+    double2_t ra[A_PER], rb0[B_PER], rb1[B_PER];
+    int iq[A_PER], ic[B_PER];                        // wave-uniform gather indices of the NEXT stage to load (A resp. B)
+    auto load_idx_A = [&](int t) {
+        const int *sq = stg_q + (int64_t)(t0 + t) * 16;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) iq[i] = sq[(wave + i * NW) / AH];
+    };
+    auto load_idx_B = [&](int t) {
+        const int *sc = stg_c + (int64_t)(t0 + t) * 16;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) ic[i] = sc[wave + i * NW];
     };
-    auto load_stage = [&](double2_t (&ra)[A_PER], double2_t (&rb)[B_PER], int tnext) {
+    auto load_A = [&]() {
+        // no per-lane predicate (a branch around a load makes the compiler drain the vm counter): lanes past the end
+        // of the row repeat its last 16 bytes
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int col2 = ((wave + i * NW) % AH) * 64 + lane;
-            if (AH * 64 == TM / 2 || col2 < TM / 2)
-                ra[i] = *reinterpret_cast<const double2_t *>(Ag + (int64_t)iq[i] * opad + 2 * col2);
+            const int col2 = min(((wave + i * NW) % AH) * 64 + lane, TM / 2 - 1);
+            ra[i] = *reinterpret_cast<const double2_t *>(Ag + (int64_t)iq[i] * opad + 2 * col2);
         }
+    };
+    auto load_B = [&](double2_t (&rb)[B_PER]) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
             rb[i] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(Bg + (int64_t)ic[i] * ldq));
-        if (tnext < nst) load_idx(tnext);            // indices of the stage after this one, a whole phase ahead of their use
     };
-    auto store_stage = [&](const double2_t (&ra)[A_PER], const double2_t (&rb)[B_PER], int buf) {
+    auto store_stage = [&](const double2_t (&rb)[B_PER], int buf) {
         double *As = smem + buf * Cfg::STAGE_DOUBLES;
         double *Bs = As + KC * LDAS;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int s = wave + i * NW, col2 = (s % AH) * 64 + lane;
-            if (AH * 64 == TM / 2 || col2 < TM / 2) *reinterpret_cast<double2_t *>(As + (s / AH) * LDAS + 2 * col2) = ra[i];
+            const int s = wave + i * NW, col2 = min((s % AH) * 64 + lane, TM / 2 - 1);
+            *reinterpret_cast<double2_t *>(As + (s / AH) * LDAS + 2 * col2) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) *reinterpret_cast<double2_t *>(Bs + (wave + i * NW) * LDBS + 2 * lane) = rb[i];
@@ -149,56 +158,84 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
     const int qcol = qt * TILE_Q + wn * 32 + lr;           // aux column of acc[.][0]; acc[.][1] is 16 further
     const int ibase = (mt * WVM + wm) * (WM * 16) + lk;    // orbital of acc[0][.][0]
     auto epilogue = [&](int p) {
-        // V: C[p][i] in accumulator layout, 2 WM loads of 16 B, the same address in all 16 lanes of a group
+        // V: C[p][i] in accumulator layout, 2 WM loads of 16 B, the same address in all 16 lanes of a group; taken two m
+        // tiles at a time (the scheduler would otherwise hold all 4 WM values in registers next to the accumulators)
         const double2_t *cv = reinterpret_cast<const double2_t *>(Cv) +
                               ((((int64_t)p * n_mt + mt) * WVM + wm) * 4 + lk) * (2 * WM);
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
-            const double2_t c01 = cv[2 * m], c23 = cv[2 * m + 1];
+        for (int m0 = 0; m0 < WM; m0 += 2) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-                vacc[n] += (acc[m][n][0] * c01.x + acc[m][n][1] * c01.y) + (acc[m][n][2] * c23.x + acc[m][n][3] * c23.y);
+            for (int m = m0; m < m0 + 2 && m < WM; ++m) {
+                const double2_t c01 = cv[2 * m], c23 = cv[2 * m + 1];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    vacc[n] += (acc[m][n][0] * c01.x + acc[m][n][1] * c01.y) + (acc[m][n][2] * c23.x + acc[m][n][3] * c23.y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        double *wrow = Wt + (int64_t)p * Wld + qcol;
+        // (p, k = i*ldq + Q) -> block (p/128, k/16), row p%128: the 16 lanes of a group write one 128-B row of a block;
+        // one orbital further = ldq/16 blocks further, and this lane's orbitals are ibase + 4 (4m + j)
+        const int64_t istep4 = (ldq >> 4) * (4 * 2048);
+        double *wp = Wt + ((int64_t)(p >> 7) * (Wld >> 4) * 128 + (p & 127)) * 16 + (int64_t)(qcol >> 4) * 2048 + lr +
+                     (int64_t)ibase * (istep4 >> 2);
+        const bool c0 = qcol < ldq, c1 = qcol + 16 < ldq;
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int i = ibase + m * 16 + 4 * j;
-                if (i < o) {
-                    if (qcol < ldq) wrow[(int64_t)i * ldq] = acc[m][0][j];
-                    if (qcol + 16 < ldq) wrow[(int64_t)i * ldq + 16] = acc[m][1][j];
+                if (ibase + m * 16 + 4 * j < o) {
+                    if (c0) wp[0] = acc[m][0][j];
+                    if (c1) wp[2048] = acc[m][1][j];
                 }
+                wp += istep4;
             }
 #pragma unroll
         for (int m = 0; m < WM; ++m) acc[m][0] = acc[m][1] = double4_t{0.0, 0.0, 0.0, 0.0};
     };
 
-    load_idx(0);
-    load_stage(ra0, rb0, 1);
-    store_stage(ra0, rb0, 0);
-    if (nst > 1) load_stage(ra1, rb1, 2);
+    // No load or LDS store of the loop is conditional: past the chunk's last stage the stage index is clamped (the
+    // last stage is loaded and staged again, nobody reads it).  A branch around a load or around the store that
+    // retires it makes the compiler's wait-count pass drain the vm counter at every phase.
+    // The gather indices of a phase's loads are fetched (scalar loads) at the END of the previous phase, just before
+    // the LDS stores and the barrier: they share the lgkm counter with the LDS reads, and a scalar load in flight at
+    // the first ds_read of a phase would hold that read's wait.
+    auto next_idx = [&](int tA, int tB) {
+        load_idx_A(min(tA, nst - 1));
+        load_idx_B(min(tB, nst - 1));
+    };
+    next_idx(0, 0);
+    load_A();                                        // stage 0
+    load_B(rb0);                                     // stage 0
+    next_idx(1, 1);
+    store_stage(rb0, 0);
+    load_B(rb1);                                     // stage 1
+    next_idx(1, 2);
     __syncthreads();
-    for (int t = 0; t < nst; t += 2) {
-        // even stage t: LDS buffer 0; set 1 holds stage t+1 (in flight); set 0 is free
-        if (t + 2 < nst) load_stage(ra0, rb0, t + 3);
+    for (int t = 0;; t += 2) {
+        // even stage t: LDS buffer 0; B set 1 holds stage t+1 (in flight); B set 0 and the A set are free
+        load_A();                                    // stage t+1.  A before B: the vm counter is in order, and the A set
+        load_B(rb0);                                 // stage t+2   is waited for at the end of THIS phase, the B set a phase later
         compute_stage(0);
         {
             const int p = stg_p[t0 + t];
             if (p >= 0) epilogue(p);
         }
-        if (t + 1 < nst) store_stage(ra1, rb1, 1);
+        next_idx(t + 2, t + 3);
+        store_stage(rb1, 1);
         __syncthreads();
         if (t + 1 >= nst) break;
-        // odd stage t+1: LDS buffer 1; set 0 holds stage t+2 (in flight); set 1 is free
-        if (t + 3 < nst) load_stage(ra1, rb1, t + 4);
+        // odd stage t+1: LDS buffer 1; B set 0 holds stage t+2 (in flight); B set 1 and the A set are free
+        load_A();                                    // stage t+2
+        load_B(rb1);                                 // stage t+3
         compute_stage(1);
         {
             const int p = stg_p[t0 + t + 1];
             if (p >= 0) epilogue(p);
         }
-        if (t + 2 < nst) store_stage(ra0, rb0, 0);
+        next_idx(t + 3, t + 4);
+        store_stage(rb0, 0);
         __syncthreads();
+        if (t + 2 >= nst) break;
     }
 
     // V partial of this (chunk, m tile, aux tile): lane groups and wave rows in fixed order
@@ -337,9 +374,11 @@ __global__ __launch_bounds__(Cfg::NT, (Cfg::NT == 256) ? 2 : 1) void k_exchange_
 #pragma unroll
         for (int n = 0; n < Cfg::WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    const double *base = Wt + (int64_t)s * KS;
-    gemm_nt_core<Cfg>(base + (int64_t)ti * Cfg::TM * Wld, Wld, base + (int64_t)tj * Cfg::TN * Wld, Wld, KS / KC, acc,
-                      smem, ti == tj);
+    // operand stage = one contiguous 16 KB block of Wb: "row stride" 16, chunk stride 128*16 doubles
+    const int64_t nkb = Wld / KC;
+    const double *base = Wt + (int64_t)s * (KS / KC) * (128 * KC);
+    gemm_nt_core<Cfg, false, true>(base + (int64_t)ti * nkb * (128 * KC), KC, base + (int64_t)tj * nkb * (128 * KC), KC, KS / KC,
+                                   acc, smem, ti == tj, !(ti == tj && (int)(threadIdx.x >> 6) == 1));
 
     double *out = Kslab + ((int64_t)s * ntri + t) * (Cfg::TM * Cfg::TN);
 #pragma unroll
@@ -450,7 +489,8 @@ __global__ void k_export_W(const double *__restrict__ Wt, int64_t Wld, int64_t l
     const int Q = (int)(idx % Ql);
     const int i = (int)((idx / Ql) % o);
     const int p = (int)(idx / ((int64_t)Ql * o));
-    out[idx] = Wt[(int64_t)p * Wld + (int64_t)i * ldq + Q];
+    const int64_t k = (int64_t)i * ldq + Q;
+    out[idx] = Wt[(((int64_t)(p >> 7) * (Wld >> 4) + (k >> 4)) * 128 + (p & 127)) * 16 + (k & 15)];
 }
 
 }  // namespace jcdf
