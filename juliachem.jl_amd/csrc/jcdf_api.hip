@@ -50,6 +50,11 @@ struct jcdf_handle {
     int64_t Np = 0, ldq = 0, Wld = 0, Plow = 0;
     int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_qt = 0, vld = 0;
     int n_chunks = 0, n_stages = 0;
+    int w_ablate = 0;                  // timing-only ablation bits of the DMA kernel (JCDF_W_ABLATE; never set in production)
+    bool w_skip_partial = true;        // DMA kernel: waves past the end of the aux rows (partial last tile) issue no MFMA
+    bool w_dma = true;                 // W kernel with LDS-DMA staging (k_exchange_W_dma) or register staging (k_exchange_W)
+    int tq = TILE_Q;                   // aux-index tile of the W kernel: 128, or 256 for the DMA kernel up to 96 orbitals
+    int kcw = KCD;                     // slots per stage of the W kernel's stage table (8 resp. 16)
     int ntri = 0, S = 0, KS = 0;
     bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
     bool dense_map = true;
@@ -146,11 +151,46 @@ void free_all(jcdf_handle *h)
 }
 
 // ---- W kernel dispatch: WMw 16-orbital MFMA row tiles per wave, WVMw wave rows ------------
+template <int WM, int WVM, int WN>
+hipError_t launch_W_dma_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
+{
+    using D = WDmaCfg<WM, WVM, WN>;
+    if (set_attr_only)     // per device: jcdf_configure runs on the handle's device
+        return hipFuncSetAttribute((const void *)k_exchange_W_dma<WM, WVM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   D::SMEM_BYTES);
+    const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
+    hipLaunchKernelGGL((k_exchange_W_dma<WM, WVM, WN>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
+                       h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+    return hipSuccess;
+}
+
+// timing-only ablations of the C20H42-shaped form (JCDF_W_ABLATE; see k_exchange_W_dma)
+template <int ABL>
+hipError_t launch_W_ablate_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
+{
+    using D = WDmaCfg<6, 1, 2>;
+    if (set_attr_only)
+        return hipFuncSetAttribute((const void *)k_exchange_W_dma<6, 1, 2, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   D::SMEM_BYTES);
+    const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
+    hipLaunchKernelGGL((k_exchange_W_dma<6, 1, 2, ABL>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
+                       h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+    return hipSuccess;
+}
+
 template <int WM, int WVM>
 hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
     using Cfg = WCfg<WM, WVM>;
-    if (set_attr_only)     // per device: jcdf_configure runs on the handle's device
+    if (h->w_dma) {
+        if constexpr (WVM == 1 && WM <= 6) {
+            if (h->tq == 256) return launch_W_dma_t<WM, WVM, 4>(h, st, set_attr_only);
+        }
+        return launch_W_dma_t<WM, WVM, 2>(h, st, set_attr_only);
+    }
+    if (set_attr_only)
         return hipFuncSetAttribute((const void *)k_exchange_W<WM, WVM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    Cfg::SMEM_BYTES);
     const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
@@ -162,6 +202,19 @@ hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 
 hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
+    if (h->w_ablate && h->w_dma && h->WVMw == 1 && h->WMw == 6 && h->tq == TILE_Q) {
+        switch (h->w_ablate) {
+            case 2: return launch_W_ablate_t<2>(h, st, attr);
+            case 4: return launch_W_ablate_t<4>(h, st, attr);
+            case 6: return launch_W_ablate_t<6>(h, st, attr);
+            case 8: return launch_W_ablate_t<8>(h, st, attr);
+            case 14: return launch_W_ablate_t<14>(h, st, attr);
+            case 16: return launch_W_ablate_t<16>(h, st, attr);
+            case 20: return launch_W_ablate_t<20>(h, st, attr);
+            case 30: return launch_W_ablate_t<30>(h, st, attr);
+            default: break;
+        }
+    }
     if (h->WVMw == 2) {
         switch (h->WMw) {
             case 5: return launch_W_t<5, 2>(h, st, attr);
@@ -223,7 +276,9 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         const int nparts = h->n_chunks * h->n_mtiles;
         hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 255) / 256)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
                            (int)h->Ql, (int)h->ldq, h->dV);
-        r.flops = 2.0 * 16.0 * (double)h->n_stages * (double)h->opad * (double)h->n_qt * TILE_Q;   // incl. all padding
+        // incl. all padding: orbitals to opad, K_p to whole stages, the aux index to whole 32-column wave tiles (DMA kernel)
+        r.flops = 2.0 * (double)h->kcw * (double)h->n_stages * (double)h->opad *
+                  (h->w_dma && h->w_skip_partial ? (double)roundup(h->ldq, h->tq / 4) : (double)h->n_qt * h->tq);
         r.alg_flops = 2.0 * Ql * P * o + 2.0 * Ql * N * o;           // the reference's 2 Q P o (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * P + 8.0 * Ql * o * N;               // B read once + W written once
         ok(hipEventRecord(r.e1, st));
@@ -707,8 +762,6 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     // same HBM channel phase
     h->ldq = roundup(h->Ql, KC);
     if (h->ldq % 512 == 0) h->ldq += KC;
-    h->n_qt = (int)((h->ldq + TILE_Q - 1) / TILE_Q);
-    h->vld = h->n_qt * TILE_Q;
     if ((size_t)h->ldq * 8 > 150 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux shard too long for the Coulomb kernel's LDS copy of V (use more shards)");
     // orbital (M) tiling of the W kernel: up to 128 orbitals -> one 4-wave workgroup holds them all;
     // more -> 8-wave workgroups of up to 256 orbitals (two wave rows share the staged B tile)
@@ -723,12 +776,28 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         if (h->WMw < 5) h->WMw = 5;
     }
     h->opad = h->n_mtiles * h->WVMw * h->WMw * 16;
+    {
+        const char *e = getenv("JCDF_W_DMA");
+        h->w_dma = !(e && atoi(e) == 0);
+        h->kcw = h->w_dma ? KCD : KC;
+        e = getenv("JCDF_W_SKIP_PARTIAL");
+        h->w_skip_partial = !(e && atoi(e) == 0);
+        e = getenv("JCDF_W_ABLATE");
+        h->w_ablate = e ? atoi(e) : 0;
+        // 256-wide aux tiles (each staged C row feeds twice the MFMAs) measured 25 % SLOWER up to 96 orbitals (C20H42
+        // shape 2.16 vs 1.70 ms: 255 VGPRs, two waves per SIMD): only on request
+        e = getenv("JCDF_W_TQ");
+        h->tq = (h->w_dma && h->WVMw == 1 && h->WMw <= 6 && h->ldq > TILE_Q && e && atoi(e) == 256) ? 256 : TILE_Q;
+    }
+    h->n_qt = (int)((h->ldq + h->tq - 1) / h->tq);
+    h->vld = h->n_qt * h->tq;
     JCDF_HIP(h, launch_W(h, nullptr, true));
 
     // ---- stage table of the W kernel + the Coulomb kernel's row list, from the packed pair list ----------------
     // For every p the kept (c, q) in packed order, in stages of KC slots; slots past K_p point at the zero row of C
     // (and at any valid row of B).  The pattern does not depend on the aux index, so this is built once.
     std::vector<int> stg_c, stg_q, stg_p, wchunk, jrow, cmap;
+    const int64_t kcw = h->kcw;
     try {
         std::vector<int64_t> pstart((size_t)N + 1, 0);
         std::vector<int> order;                       // packed indices grouped by p (stable); empty: already grouped
@@ -750,21 +819,22 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         cmap.assign((size_t)(N * N), -1);
         jrow.reserve((size_t)(P / 2 + N));
         int64_t total_stages = 0;
-        for (int64_t p = 0; p < N; ++p) total_stages += std::max<int64_t>(1, (pstart[(size_t)p + 1] - pstart[(size_t)p] + KC - 1) / KC);
-        stg_c.reserve((size_t)total_stages * KC);
-        stg_q.reserve((size_t)total_stages * KC);
+        for (int64_t p = 0; p < N; ++p) total_stages += std::max<int64_t>(1, (pstart[(size_t)p + 1] - pstart[(size_t)p] + kcw - 1) / kcw);
+        stg_c.reserve((size_t)total_stages * kcw);
+        stg_q.reserve((size_t)total_stages * kcw);
         stg_p.reserve((size_t)total_stages);
-        // ~16 workgroups per resident slot (2 per CU), at least one p and >= 16 stages each
+        // ~6 workgroups per resident slot (2 per CU), at least one p and >= 256 contraction rows each: a workgroup's
+        // pipeline fill is paid once per chunk (C20H42 shape: 64 stages per chunk 1.76 ms, 128: 1.66, 512: 1.64)
         const int64_t tiles = total_stages * h->n_qt * h->n_mtiles;
-        int64_t target = std::min<int64_t>(256, std::max<int64_t>(16, tiles / (16 * 2 * (int64_t)h->num_cu)));
+        int64_t target = std::min<int64_t>(4096 / kcw, std::max<int64_t>(256 / kcw, tiles / (6 * 2 * (int64_t)h->num_cu)));
         if (const char *e = getenv("JCDF_W_CHUNK_STAGES")) target = std::max(1, atoi(e));
         wchunk.push_back(0);
         int64_t in_chunk = 0;
         for (int64_t p = 0; p < N; ++p) {
             const int64_t k0 = pstart[(size_t)p], Kp = pstart[(size_t)p + 1] - k0;
-            const int64_t ns = std::max<int64_t>(1, (Kp + KC - 1) / KC);
+            const int64_t ns = std::max<int64_t>(1, (Kp + kcw - 1) / kcw);
             int last_c = 0;
-            for (int64_t j = 0; j < ns * KC; ++j) {
+            for (int64_t j = 0; j < ns * kcw; ++j) {
                 if (j < Kp) {
                     const int64_t c = order.empty() ? k0 + j : order[(size_t)(k0 + j)];
                     const int64_t q = pq_q ? pq_q[c] : j;
@@ -827,7 +897,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
 
     int32_t rc;
     // KC rows + one aux tile of slack: a partial last aux tile reads past the end of its rows
-    if ((rc = dev_alloc(h, &h->dB, (h->P + KC) * h->ldq + 2 * TILE_Q, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dB, (h->P + KC) * h->ldq + 4 * TILE_Q, true))) return rc;
     if ((rc = dev_alloc(h, &h->dCpad, (h->Np + KC) * h->opad, true))) return rc;
     if ((rc = dev_alloc(h, &h->dCv, N * h->opad, true))) return rc;
     if ((rc = dev_alloc(h, &h->dWt, h->Np * h->Wld, true))) return rc;
@@ -908,7 +978,7 @@ int32_t jcdf_push_three_center(jcdf_handle *h, int64_t s0, int64_t s1, const dou
     if (!T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center: bad row range");
     JCDF_HIP(h, hipSetDevice(h->device));
     if (!h->pushed_any) {
-        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 2 * TILE_Q) * 8, h->stream));
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 4 * TILE_Q) * 8, h->stream));
         h->pushed_any = true;
     }
     if (s0 >= h->q1) return JCDF_OK;                 // Linv[q0:q1, s0:s1] == 0 (lower triangular)
@@ -925,7 +995,7 @@ int32_t jcdf_push_three_center_device(jcdf_handle *h, int64_t s0, int64_t s1, co
     if (!d_T || s0 < 0 || s1 <= s0 || s1 > h->Qtot) return fail(h, JCDF_ERR_INVALID, "jcdf_push_three_center_device: bad row range");
     JCDF_HIP(h, hipSetDevice(h->device));
     if (!h->pushed_any) {
-        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 2 * TILE_Q) * 8, h->stream));
+        JCDF_HIP(h, hipMemsetAsync(h->dB, 0, (size_t)((h->P + KC) * h->ldq + 4 * TILE_Q) * 8, h->stream));
         h->pushed_any = true;
     }
     if (s0 >= h->q1) return JCDF_OK;

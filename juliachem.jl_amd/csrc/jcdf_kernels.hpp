@@ -256,6 +256,235 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_exchange_W_dma: the same contraction with LDS-DMA staging (global_load_lds_dwordx4: global -> LDS with no
+// VGPR in between).  Stages of KCD = 8 slots in a ring of 4 LDS buffers; the DMA of stage t+3 is issued at the
+// start of phase t, a counted `s_waitcnt vmcnt` at the end of phase t retires stage t+1 (stages t+2 and t+3 stay in
+// flight across the raw s_barrier), and stage t+1 is read in phase t+1 — one phase after the wait that retires it.
+// One wave instruction moves one 1 KB row piece: a B row (128 aux indices) or 128 orbitals of a C row; LDS rows are
+// padded to 144 / 272 doubles (conflict-free ds_read_b64, no piece crosses a row).  No staging registers, no
+// ds_write, no branch around a load; the stage table has 8-slot granularity (K_p rounded up to 8 instead of 16).
+// ---------------------------------------------------------------------------
+constexpr int KCD = 8;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+#ifndef JCDF_W_DMA_WAVES3
+#define JCDF_W_DMA_WAVES3 1
+#endif
+// WN = 16-column MFMA tiles per wave along the aux index: 2 (aux tile 128) or 4 (aux tile 256: every staged C row
+// feeds twice as many MFMAs — up to 96 orbitals the kernel is bound by the bytes it moves into LDS, half of which
+// are C rows, not by MFMA issue: skipping 5 % of the MFMAs did not change its time).
+template <int WM, int WVM, int WN>
+struct WDmaCfg {
+    static constexpr int TM = 16 * WM * WVM, TN = 64 * WN;
+    static constexpr int AH = (TM <= 128) ? 1 : 2;                  // 1 KB pieces per C row
+    static constexpr int BH = TN / 128;                             // 1 KB pieces per B row
+    // LDS row strides (doubles): >= the row, and = 16 mod 32 (conflict-free ds_read_b64 across the 4 k rows of an MFMA step)
+    static constexpr int LDAS = ((TM + 15) / 32) * 32 + 16, LDBS = TN + 16;
+    // up to 96 orbitals the 128-wide form fits 3 workgroups per CU (<= 168 VGPRs, 3 x 48 KB of LDS with a ring of 3)
+    static constexpr bool THREE = JCDF_W_DMA_WAVES3 && WVM == 1 && WM <= 6 && WN == 2;
+    static constexpr int RING = (THREE || WN == 4) ? 3 : 4;
+    static constexpr int WAVES_PER_SIMD = THREE ? 3 : 2;
+    static constexpr int STAGE_DOUBLES = KCD * (LDAS + LDBS);
+    static constexpr int SMEM_BYTES = RING * STAGE_DOUBLES * 8;
+    static constexpr int NW = 4 * WVM, NT = 64 * NW;
+    static constexpr int A_PER = KCD * AH / NW, B_PER = KCD * BH / NW;   // pieces per wave and stage
+    static constexpr int G = A_PER + B_PER;
+    static constexpr int STORES = WM * 4 * WN;                      // W stores per wave in an epilogue
+    static_assert((KCD * AH) % NW == 0 && (KCD * BH) % NW == 0, "stage rows do not divide over the waves");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ABL: timing-only ablation bits (tools/prof_fock.py with JCDF_W_ABLATE, C20H42-shaped <6,1,2> only; results are wrong
+// with them; they are template bits because a run-time flag around the DMA issue or the wait de-pipelines the loop:
+// the same kernel took 5.05 instead of 1.70 ms): 2 = no DMA after the prologue, 4 = no wait / barrier in the loop,
+// 8 = no W stores, 16 = no MFMA.
+template <int WM, int WVM, int WN, int ABL = 0>
+__global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) void k_exchange_W_dma(
+    const double *__restrict__ Bp, int64_t ldq, const double *__restrict__ Cpad, const double *__restrict__ Cv,
+    double *__restrict__ Wt, int64_t Wld, double *__restrict__ vpart, int vld, int o, int opad, int n_mt, int n_qt,
+    const int *__restrict__ wchunk, const int *__restrict__ stg_c, const int *__restrict__ stg_q,
+    const int *__restrict__ stg_p, int skip_partial)
+{
+    using D = WDmaCfg<WM, WVM, WN>;
+    constexpr int TM = D::TM, TN = D::TN, LDAS = D::LDAS, LDBS = D::LDBS, NW = D::NW, AH = D::AH, BH = D::BH;
+    constexpr int A_PER = D::A_PER, B_PER = D::B_PER, G = D::G, RING = D::RING;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    const int b = blockIdx.x;
+    const int qt = b % n_qt, mt = (b / n_qt) % n_mt, chunk = b / (n_qt * n_mt);
+    const int t0 = wchunk[chunk], nst = wchunk[chunk + 1] - t0;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 4, wn = wave % 4;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    double4_t acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double vacc[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) vacc[n] = 0.0;
+
+    // a wave whose aux columns all lie past the end of the rows (last, partial aux tile) issues no MFMA and no
+    // store; it still moves its DMA pieces and meets every barrier
+    const bool active = !skip_partial || qt * TN + wn * (16 * WN) < ldq;
+    const double *Ag = Cpad + mt * TM + 2 * lane;
+    const double *Bg = Bp + (int64_t)qt * TN + 2 * lane;
+
+    int iq[A_PER], ic[B_PER];                        // wave-uniform gather indices of the next stage to issue
+    auto next_idx = [&](int t) {
+        const int ts = min(t, nst - 1);              // past the chunk's end the last stage is issued again (nobody reads it)
+        const int *sq = stg_q + (int64_t)(t0 + ts) * KCD, *sc = stg_c + (int64_t)(t0 + ts) * KCD;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) iq[i] = sq[(wave + i * NW) / AH];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) ic[i] = sc[(wave + i * NW) / BH];
+    };
+    auto issue = [&](int buf) {
+        double *As = smem + buf * D::STAGE_DOUBLES;
+        double *Bs = As + KCD * LDAS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int s = wave + i * NW, row = s / AH, half = s % AH;
+            // lanes past the row's orbitals are masked off: their 16 bytes would land in the next LDS row
+            if (TM % 128 == 0 || half * 64 + lane < TM / 2)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(Ag + (int64_t)iq[i] * opad + half * 128),
+                                                 (lds_void_t *)(As + row * LDAS + half * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int s = wave + i * NW, row = s / BH, half = s % BH;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(Bg + (int64_t)ic[i] * ldq + half * 128),
+                                             (lds_void_t *)(Bs + row * LDBS + half * 128), 16, 0, 2);   // nt: read once
+        }
+    };
+    auto compute_stage = [&](int buf) {
+        if (!active) return;
+        const double *As = smem + buf * D::STAGE_DOUBLES + wm * (WM * 16) + lr;
+        const double *Bs = smem + buf * D::STAGE_DOUBLES + KCD * LDAS + wn * (16 * WN) + lr;
+#pragma unroll
+        for (int ks = 0; ks < KCD / 4; ++ks) {
+            double a[WM], bb[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) a[m] = As[(ks * 4 + lk) * LDAS + m * 16];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bb[n] = Bs[(ks * 4 + lk) * LDBS + n * 16];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    if constexpr (ABL & 16) {       // keep the LDS reads alive without the matrix pipe
+                        asm volatile("" ::"v"(a[m]), "v"(bb[n]));
+                    } else {
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[n], acc[m][n], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    const int qcol = qt * TN + wn * (16 * WN) + lr;         // aux column of acc[.][0]; acc[.][n] is 16 n further
+    const int ibase = (mt * WVM + wm) * (WM * 16) + lk;     // orbital of acc[0][.][0]
+    auto epilogue = [&](int p) {
+        // V: C[p][i] in accumulator layout, 2 WM loads of 16 B, the same address in all 16 lanes of a group; taken two m
+        // tiles at a time (the scheduler would otherwise hold all 4 WM values in registers next to the accumulators)
+        const double2_t *cv = reinterpret_cast<const double2_t *>(Cv) +
+                              ((((int64_t)p * n_mt + mt) * WVM + wm) * 4 + lk) * (2 * WM);
+#pragma unroll
+        for (int m0 = 0; m0 < WM; m0 += 2) {
+#pragma unroll
+            for (int m = m0; m < m0 + 2 && m < WM; ++m) {
+                const double2_t c01 = cv[2 * m], c23 = cv[2 * m + 1];
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    vacc[n] += (acc[m][n][0] * c01.x + acc[m][n][1] * c01.y) + (acc[m][n][2] * c23.x + acc[m][n][3] * c23.y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (p, k = i*ldq + Q) -> block (p/128, k/16), row p%128: the 16 lanes of a group write one 128-B row of a block;
+        // one orbital further = ldq/16 blocks further, and this lane's orbitals are ibase + 4 (4m + j)
+        const int64_t istep4 = (ldq >> 4) * (4 * 2048);
+        double *wp = Wt + ((int64_t)(p >> 7) * (Wld >> 4) * 128 + (p & 127)) * 16 + (int64_t)(qcol >> 4) * 2048 + lr +
+                     (int64_t)ibase * (istep4 >> 2);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ibase + m * 16 + 4 * j < o && !(ABL & 8)) {
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        if (qcol + 16 * n < ldq) wp[2048 * n] = acc[m][n][j];
+                }
+                wp += istep4;
+            }
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    };
+
+    // prologue: stages 0 .. RING-2 in flight, stage 0 retired
+    constexpr int AHEAD = RING - 1;                  // the DMA of stage t + AHEAD is issued at the start of phase t
+    constexpr int FLY = (AHEAD - 1) * G;             // pieces that stay in flight across a barrier
+    next_idx(0);
+#pragma unroll
+    for (int s0 = 0; s0 < AHEAD; ++s0) {
+        issue(s0);
+        next_idx(s0 + 1);
+    }
+    wait_vmcnt<FLY>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = AHEAD;                        // ring slots of stage t and of stage t + AHEAD
+    for (int t = 0; t < nst; ++t) {
+        if constexpr (!(ABL & 2)) issue(nxt);        // -> the buffer phase t-1 has finished reading
+        compute_stage(cur);
+        const int p = stg_p[t0 + t];
+        next_idx(t + AHEAD + 1);
+        if (p >= 0 && active) {
+            epilogue(p);
+            // behind stage t+1's pieces the counter now holds FLY pieces and this wave's W stores
+            if constexpr (!(ABL & 4)) wait_vmcnt<(FLY + D::STORES > 63) ? 63 : FLY + D::STORES>();
+        } else {
+            if constexpr (!(ABL & 4)) wait_vmcnt<FLY>();
+        }
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        cur = (cur + 1 == RING) ? 0 : cur + 1;
+        nxt = (nxt + 1 == RING) ? 0 : nxt + 1;
+    }
+    wait_vmcnt<0>();                                 // the re-issued tail stages still write this workgroup's LDS
+
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        vacc[n] += __shfl_xor(vacc[n], 16, 64);
+        vacc[n] += __shfl_xor(vacc[n], 32, 64);
+    }
+    if (WVM == 2) {
+        __builtin_amdgcn_s_barrier();                // every wave's DMA has landed (vmcnt(0) above) before the LDS is reused
+        if (wm == 1 && lk == 0) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n) smem[wn * (16 * WN) + 16 * n + lr] = vacc[n];
+        }
+        __syncthreads();
+        if (wm == 0) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n) vacc[n] += smem[wn * (16 * WN) + 16 * n + lr];
+        }
+    }
+    if (wm == 0 && lk == 0) {
+        double *vp = vpart + ((int64_t)chunk * n_mt + mt) * vld + qcol;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) vp[16 * n] = vacc[n];
+    }
+}
+
 // V[Q] = sum over the W kernel's partials, fixed order; entries Ql <= Q < ldq are set to 0.
 __global__ void k_reduce_V(const double *__restrict__ vpart, int nparts, int vld, int Ql, int ldq, double *__restrict__ V)
 {
