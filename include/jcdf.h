@@ -134,6 +134,10 @@ int32_t jcdf_push_three_center_device(jcdf_handle *h, int64_t s0, int64_t s1, co
  * B = L^-1 T ((q1-q0) x P column-major), e.g. from the reference's CPU path
  * (ScreenedDF.jl:103). */
 int32_t jcdf_set_B(jcdf_handle *h, const double *B);
+/* The same for packed columns [c0,c1) of that matrix, already on this handle's device ((q1-q0) x (c1-c0)
+ * column-major): B formed elsewhere on the device, or a tensor too large to stage on the host (a 154 GB B is set
+ * in column blocks).  The caller covers [0,P). */
+int32_t jcdf_set_B_columns_device(jcdf_handle *h, int64_t c0, int64_t c1, const double *d_B);
 /* Read back this shard of B in the reference layout ((q1-q0) x P col-major). */
 int32_t jcdf_get_B(jcdf_handle *h, double *B_out);
 

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "jcdf_push_three_center_device": (C.c_int32, [_P, _I64, _I64, _P]),
     "jcdf_set_B": (C.c_int32, [_P, _P]),
     "jcdf_get_B": (C.c_int32, [_P, _P]),
+    "jcdf_set_B_columns_device": (C.c_int32, [_P, C.c_int64, C.c_int64, _P]),
     "jcdf_set_core_hamiltonian": (C.c_int32, [_P, _P]),
     "jcdf_fock_build": (C.c_int32, [_P, _P, _P, C.POINTER(jcdf_timings)]),
     "jcdf_fock_build_begin": (C.c_int32, [_P, _P]),

@@ -1020,6 +1020,20 @@ int32_t jcdf_set_B(jcdf_handle *h, const double *B)
     return JCDF_OK;
 }
 
+int32_t jcdf_set_B_columns_device(jcdf_handle *h, int64_t c0, int64_t c1, const double *d_B)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !d_B) return fail(h, JCDF_ERR_INVALID, "jcdf_set_B_columns_device: configure first / NULL");
+    if (c0 < 0 || c1 <= c0 || c1 > h->P) return fail(h, JCDF_ERR_INVALID, "jcdf_set_B_columns_device: bad packed-index range");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    JCDF_HIP(h, hipMemcpy2DAsync(h->dB + c0 * h->ldq, (size_t)h->ldq * 8, d_B, (size_t)h->Ql * 8, (size_t)h->Ql * 8,
+                                 (size_t)(c1 - c0), hipMemcpyDeviceToDevice, h->stream));
+    JCDF_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_B = true;
+    h->pushed_any = true;
+    return JCDF_OK;
+}
+
 int32_t jcdf_get_B(jcdf_handle *h, double *B_out)
 {
     if (!h) return JCDF_ERR_INVALID;

@@ -384,6 +384,10 @@ class JCDFHandle:
         assert a.shape == (self.Ql, self.P)
         self._check(self._lib.jcdf_set_B(self._h, a.ctypes.data))
 
+    def set_B_columns_device(self, c0: int, c1: int, d_ptr: int) -> None:
+        """packed columns [c0,c1) of B, (Ql x (c1-c0)) column-major, already on the device"""
+        self._check(self._lib.jcdf_set_B_columns_device(self._h, c0, c1, d_ptr))
+
     def get_B(self) -> np.ndarray:
         out = np.empty((self.Ql, self.P), dtype=np.float64, order="F")
         self._check(self._lib.jcdf_get_B(self._h, out.ctypes.data))

@@ -63,6 +63,31 @@ def band_mask(N: int, kept_fraction: float, rng: np.random.Generator) -> np.ndar
     return m
 
 
+def cluster_mask(N: int, kept_fraction: float, rng: np.random.Generator, per_site: int = 5) -> np.ndarray:
+    """Scattered symmetric keep-mask of a compact 3-D cluster, the pattern a Schwarz test leaves on something like
+    (H2O)50: `per_site` consecutive functions share a random site in a cube (sites sorted along a Morton curve, as
+    rhf.spatial_order sorts atoms), a pair is kept iff its sites are closer than a cut-off chosen by bisection so that
+    kept/N^2 ~ kept_fraction.  Every row keeps a different, non-contiguous set of partners."""
+    ns = (N + per_site - 1) // per_site
+    R = rng.random((ns, 3))
+    cell = np.minimum((R * 8).astype(np.int64), 7)
+    key = np.zeros(ns, dtype=np.int64)
+    for bit in range(3):
+        for d in range(3):
+            key |= ((cell[:, d] >> bit) & 1) << (3 * bit + d)
+    R = R[np.argsort(key, kind="stable")]
+    site = np.minimum(np.arange(N) // per_site, ns - 1)
+    d2 = ((R[:, None, :] - R[None, :, :]) ** 2).sum(-1)
+    lo, hi = 0.0, 3.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        frac = (d2[np.ix_(site, site)] < mid).mean()
+        lo, hi = (mid, hi) if frac < kept_fraction else (lo, mid)
+    m = d2[np.ix_(site, site)] < hi
+    np.fill_diagonal(m, True)
+    return m
+
+
 def make(N: int, Q: int, n_occ: int, seed: int = SEED, kept_fraction: Optional[float] = None,
          dtype=np.float64) -> SyntheticDF:
     rng = np.random.default_rng(seed)

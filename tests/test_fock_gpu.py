@@ -87,11 +87,16 @@ def test_not_spd_metric_is_an_error():
     h.close()
 
 
-@pytest.mark.parametrize("N,Q,o,kept", [(40, 30, 6, 0.5), (150, 64, 20, 0.47), (257, 48, 9, 0.3)])
+@pytest.mark.parametrize("N,Q,o,kept", [(40, 30, 6, 0.5), (150, 64, 20, 0.47), (257, 48, 9, 0.3),
+                                        (300, 70, 33, -0.13), (200, 140, 130, -0.13)])
 def test_screened_packed_parity(N, Q, o, kept):
     """Packed (Schwarz-screened) layout of the reference in, same F out as the
-    reference's screened CPU algorithm (ScreenedDF.jl)."""
-    s = synthetic.make(N, Q, o, seed=9, kept_fraction=kept)
+    reference's screened CPU algorithm (ScreenedDF.jl).  kept < 0: a |kept| scattered 3-D-cluster map (every row
+    keeps a different, non-contiguous set of partners) instead of a band; the device tensor and the executed W
+    flops must then follow the kept pairs (GPUDF.jl:111-155: device_B is (Q_d, P); 2 Q P o flops, :637-667)."""
+    s = synthetic.make(N, Q, o, seed=9, kept_fraction=abs(kept))
+    if kept < 0:
+        s.mask = synthetic.cluster_mask(N, -kept, np.random.default_rng(5), per_site=3)
     sd = orc.get_screening_metadata(s.mask)
     B = orc.calculate_B(s.J2c, s.T)
     Bp = orc.pack_three_center(B, sd)
@@ -103,12 +108,50 @@ def test_screened_packed_parity(N, Q, o, kept):
     F, _ = h.fock_build(Co)
     assert _rel(F, ref) < RTOL
     assert _rel(h.get_B(), Bp) < 1e-15
+    P = Bp.shape[1]
+    w = {k["name"]: k for k in h.kernel_stats()}["k_exchange_W"]
+    assert w["alg_flops"] == pytest.approx(2.0 * Q * P * o + 2.0 * Q * N * o)
+    if kept < 0:
+        assert P < 0.2 * N * N
+        # executed = 2 (aux rounded to the wave tile) (sum_p K_p rounded to whole stages) (orbitals rounded to 16)
+        assert w["flops"] < 2.0 * (Q + 32) * (P + 16 * N) * (16 * ((o + 15) // 16)) * 1.001
     # and through the metric path with packed T
     h2 = _handle(N, Q, 0, Q, o, (sd.pq_p, sd.pq_q))
     h2.set_metric(np.tril(s.J2c))
     h2.push_three_center(0, Q, np.asfortranarray(orc.pack_three_center(s.T, sd)))
     h2.set_core_hamiltonian(s.H)
     F2, _ = h2.fock_build(Co)
+    assert _rel(F2, ref) < RTOL
+    h.close(); h2.close()
+
+
+def test_second_B_formation_on_one_handle_and_column_setter():
+    """A new metric starts a new B (jcdf.h: the first push after jcdf_set_metric zeroes B): forming B twice on one
+    configured handle — new geometry, same sizes — must not accumulate onto the old tensor.  Also the device-side
+    column setter against jcdf_set_B."""
+    import torch
+    N, Q, o = 60, 90, 7
+    h = _handle(N, Q, 0, Q, o)
+    for seed in (3, 4):
+        s = synthetic.make(N, Q, o, seed=seed)
+        h.set_metric(np.tril(s.J2c))
+        for s0 in range(0, Q, 32):
+            s1 = min(Q, s0 + 32)
+            h.push_three_center(s0, s1, np.asfortranarray(s.T.reshape(Q, N * N, order="F")[s0:s1]))
+        h.set_core_hamiltonian(s.H)
+        F, _ = h.fock_build(s.C[:, :o])
+        B = orc.calculate_B(s.J2c, s.T)
+        ref = s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :o])
+        assert _rel(F, ref) < RTOL, seed
+    Bm = np.asfortranarray(B.reshape(Q, N * N, order="F"))
+    h2 = _handle(N, Q, 0, Q, o)
+    for c0 in range(0, N * N, 1000):
+        c1 = min(N * N, c0 + 1000)
+        blk = torch.as_tensor(np.ascontiguousarray(Bm[:, c0:c1].T), device="cuda:0")     # [c][Q] == (Q x nc) column-major
+        h2.set_B_columns_device(c0, c1, blk.data_ptr())
+    assert np.array_equal(h2.get_B(), Bm)
+    h2.set_core_hamiltonian(s.H)
+    F2, _ = h2.fock_build(s.C[:, :o])
     assert _rel(F2, ref) < RTOL
     h.close(); h2.close()
 
