@@ -10,4 +10,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
     -I"$ROOT/include" \
     "$PKG/csrc/jcdf_api.hip" "$PKG/csrc/jcint_host.cpp" -o "$PKG/lib/libjcdf_hip.so" "$@"
 gcc -O2 -fPIC -shared -o "$ROOT/oracle/_build/libjcdf_oracle.so" "$ROOT/oracle/c/jcdf_oracle.c"
-echo "built: $PKG/lib/libjcdf_hip.so  $ROOT/oracle/_build/libjcdf_oracle.so"
+# CPU baseline of bench.py (the reference's two CPU modes on the host BLAS found at run time); checker/bench code only
+gcc -O2 -fPIC -shared -fopenmp -o "$ROOT/oracle/_build/libjcdf_cpu_baseline.so" "$ROOT/oracle/c/jcdf_cpu_baseline.c" -ldl
+echo "built: $PKG/lib/libjcdf_hip.so  $ROOT/oracle/_build/libjcdf_oracle.so  $ROOT/oracle/_build/libjcdf_cpu_baseline.so"

@@ -67,7 +67,7 @@ class DeviceEigh:
         """Fp: symmetric (n, n) device tensor.  Returns (eigenvalues ascending, U with
         eigenvectors in columns), like torch.linalg.eigh."""
         self.calls += 1
-        if not self.ok:
+        if not self.ok:                                           # counted in `fallbacks` when the switch happened; see `reason`
             return torch.linalg.eigh(Fp)
         n = self.n
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -119,6 +119,7 @@ class DeviceEigh:
         bad = err != 0 or int(self.info.item()) != 0
         if bad:
             self.ok = False
+            self.fallbacks += 1
             self.reason = "sytrd barrier timeout" if err else "stedc info=%d" % int(self.info.item())
         return not bad
 

@@ -61,13 +61,14 @@ def _broadcast(dist, t, src: int) -> None:
         dist.broadcast(t, src)
 
 
-def _all_reduce(dist, t) -> None:
+def _all_reduce(dist, t, op=None) -> None:
+    kw = {} if op is None else {"op": op}
     if _staged(dist, t):
         tmp = t.cpu()
-        dist.all_reduce(tmp)
+        dist.all_reduce(tmp, **kw)
         t.copy_(tmp)
     else:
-        dist.all_reduce(t)
+        dist.all_reduce(t, **kw)
 
 
 def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int, dist, T_own, alloc, push) -> None:
@@ -116,6 +117,8 @@ class DeviceFockBuilder:
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
         self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
+        self.time_collectives = False      # bench: device events around the broadcast of C and the all-reduce of F
+        self.collective_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
 
     # ---- setup -----------------------------------------------------------------
     def set_metric(self, J2c: np.ndarray) -> None:
@@ -141,9 +144,37 @@ class DeviceFockBuilder:
     # ---- per iteration -----------------------------------------------------------
     def build(self, C_occ_dev: torch.Tensor) -> torch.Tensor:
         """C_occ_dev: (n_occ, N) row-major device tensor == (N, n_occ) column-major,
-        the layout of DensityFitting.jl:49.  Returns the reduced F (device)."""
+        the layout of DensityFitting.jl:49.  Returns the reduced F (device).
+        With more than one rank the coefficients are first broadcast from rank 0 — MPI.Bcast!(C, 0) of SCF.jl:462 —
+        so that every shard is built from the same bits even if a rank's replicated eigensolve took another route."""
+        if self.world > 1:
+            ev = self._collective_begin()
+            _broadcast(self.dist, C_occ_dev, 0)
+            self._collective_end(ev)
         self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr())
-        return allreduce_fock(self.F, self.world, self.dist)   # RCCL ncclAllReduce(N^2 fp64) over xGMI
+        ev = self._collective_begin()
+        out = allreduce_fock(self.F, self.world, self.dist)    # RCCL ncclAllReduce(N^2 fp64) over xGMI
+        self._collective_end(ev)
+        return out
+
+    def _collective_begin(self):
+        if not (self.time_collectives and self.world > 1):
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _collective_end(self, ev) -> None:
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.collective_events.append((ev, e1))
+
+    def collective_ms(self) -> float:
+        """sum of the recorded collective durations (ms); clears the record.  Call after a device synchronise."""
+        tot = sum(a.elapsed_time(b) for a, b in self.collective_events)
+        self.collective_events = []
+        return float(tot)
 
     def close(self) -> None:
         self.h.close()
@@ -194,7 +225,7 @@ class DeviceSCF:
         self.sp2_skip = True
         self.F = self.H.clone()
         self.D = torch.zeros_like(self.H)
-        self._diag()                                               # "iteration 0", SCF.jl:178-181
+        self._checked_diag()                                       # "iteration 0", SCF.jl:178-181
         self.F_old = self.F.clone()
         self.E_old, self.dE, self.B_dim, self.iter = 0.0, 1.0, 1, 1
         # DIIS history: ring buffers on the device (slot of the newest entry = head); the small
@@ -235,6 +266,24 @@ class DeviceSCF:
             self.canonical = True
         self.D = 2.0 * (self.Co_t.T @ self.Co_t)
 
+    def _checked_diag(self) -> None:
+        """Eigensolve whose status is read at once (one host sync): used where no scf tail follows — iteration 0 and
+        canonical_orbitals().  A hand-off timeout / stedc failure is counted (eigh.fallbacks), reported by
+        `solver_report()`, and the step is redone with the vendor solver; all ranks redo together."""
+        self._diag(False)
+        bad = self.eigh.status()
+        if self.fb.world > 1:
+            _all_reduce(self.fb.dist, bad, self.fb.dist.ReduceOp.MAX)
+        if float(bad.item()) != 0.0:
+            self.eigh.check()                                      # flips the failing rank to the vendor solver, counted
+            self._diag(False)
+
+    def solver_report(self) -> dict:
+        """What the replicated eigensolves of this SCF actually ran on (no silent fallback)."""
+        e = self.eigh
+        return {"eigensolves": e.calls, "library_path": bool(e.ok), "vendor_fallbacks": e.fallbacks,
+                "reason": getattr(e, "reason", None)}
+
     def _orthonormalise(self, Yt: torch.Tensor):
         """rows of Yt (o, N) -> L^-1 Yt with Yt Yt^T = L L^T; also the smallest pivot (1-element device tensor)"""
         o = Yt.shape[0]
@@ -264,15 +313,29 @@ class DeviceSCF:
                                             p(self.tail_work), p(self.tail_out))
         if rc != 0:
             raise RuntimeError("jcdf_scf_tail_device failed (status %d)" % rc)
+        if self.fb.world > 1:
+            # every rank must take the same decisions (convergence, DIIS reset, fallbacks) or the next collective hangs:
+            # trouble flags are OR-ed over the ranks, everything else is rank 0's record
+            rec, dist = self.tail_out, self.fb.dist
+            trouble = torch.zeros(2, dtype=torch.float64, device=rec.device)
+            trouble[0] = (rec[3] != 0).to(torch.float64)
+            if use_sp2:
+                good = (rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & (rec[6] > 1e-2) & torch.isfinite(rec[0])
+                trouble[1] = (~good).to(torch.float64)
+            _all_reduce(dist, trouble, dist.ReduceOp.MAX)
+            _broadcast(dist, rec, 0)
+            rec[3] = trouble[0]
+            if use_sp2:
+                rec[4] = torch.where(trouble[1] != 0, torch.zeros_like(rec[4]), rec[4])
         return self.tail_out.cpu().tolist()
 
     def canonical_orbitals(self) -> None:
         """Eigenvectors / eigenvalues of the current Fock matrix into self.C / self.eps (what the reference has after
         every iteration; with density_solver = "sp2" only on request)."""
         if not self.canonical:
-            self.eps, U = self.eigh(self.X @ self.F @ self.X)
-            self.C = self.X @ U
-            self.canonical = True
+            D = self.D
+            self._checked_diag()                                   # sets C, eps (and D, Co_t: the same space)
+            self.D = D
 
     profile = False
 
@@ -372,7 +435,8 @@ class DeviceSCF:
                 self.sp2_reasons[why] = self.sp2_reasons.get(why, 0) + 1
                 self._diag(False)
                 e_h, drms, _, eig_bad = self._tail(D_old, False)[:4]
-        if eig_bad and not self.eigh.check():                      # hand-off timeout / stedc failure: redo with the vendor solver
+        if eig_bad:                                                # hand-off timeout / stedc failure on some rank: all ranks redo,
+            self.eigh.check()                                      # the failing one with the vendor solver (counted, solver_report)
             self._diag(False)
             e_h, drms = self._tail(D_old, False)[:2]
         self.sp2_skip = not (drms < 15.0)       # occupied space still turning by ~90 degrees somewhere: no basis to project

@@ -17,10 +17,11 @@ from .integrals import HostIntegralEngine
 
 
 def spatial_order(atoms: Sequence[Dict], cell: float = 4.0) -> List[int]:
-    """Atom order along a Z-order (Morton) curve through cells of `cell` bohr.  The library keeps B dense-with-zeros and
-    skips whole 16 x 128 tiles without a kept (q, p) pair (jcdf_configure); with atoms in arbitrary input order the
-    Schwarz-kept pairs are scattered over the whole index space and no tile is empty, with neighbours adjacent they
-    gather around the diagonal.  Energies do not depend on the order; results are returned in the caller's order."""
+    """Atom order along a Z-order (Morton) curve through cells of `cell` bohr.  The device tensor is the reference's
+    packed (Q_d, P) matrix, so memory and work follow the kept pairs in ANY order; with neighbours adjacent the kept q
+    of a p come in a few long runs, i.e. the W kernel's row gather reads long contiguous stretches of B and of C, and
+    the aux shards of neighbouring ranks' shells stay spatially compact.  Energies do not depend on the order;
+    results are returned in the caller's order."""
     R = np.asarray([a["center"] for a in atoms], dtype=np.float64)
     q = np.floor((R - R.min(axis=0)) / cell).astype(np.int64)
 
@@ -114,8 +115,11 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     converged = False
     E = 0.0
     it = 0
+    it_times = []
     for it in range(1, opts.df_max_iterations + 1):                         # SCF.jl:399-573, 596-604
+        t_it = time.perf_counter()
         E, dE, drms = scf.step()
+        it_times.append(time.perf_counter() - t_it)                         # step() ends with its one host sync
         if output >= 2 and fb.rank == 0:
             print("%d      %.10f      %.10f      %.10f" % (it, E, dE, drms))
         if abs(dE) <= opts.df_energy_convergence and drms <= opts.df_density_convergence:
@@ -134,7 +138,8 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     out = {"Fock": sym(scf.F.cpu().numpy()), "Density": sym(scf.D.cpu().numpy()), "Energy-Weighted Density": sym(W),
            "MO Coeff": np.ascontiguousarray(C[u, :]), "Overlap": sym(S), "Energy": E, "Converged?": converged, "Timings": jc_timing,
            "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail),
-           "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes(),
+           "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes(), "Iteration Times": it_times,
+           "Eigensolver": scf.solver_report(),
            "Density Solver": {"name": scf.density_solver, "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks,
                               "sp2_fallback_reasons": dict(scf.sp2_reasons)}}
     fb.close()

@@ -110,3 +110,26 @@ def make(N: int, Q: int, n_occ: int, seed: int = SEED, kept_fraction: Optional[f
 def make_config(name: str, **kw) -> SyntheticDF:
     N, Q, o = CONFIGS[name]
     return make(N, Q, o, **kw)
+
+
+def n_alkane(nc: int) -> List[dict]:
+    """Idealised all-trans n-alkane C_nc H_(2nc+2) (C-C 1.53 A, C-C-C 112 deg, C-H 1.09 A, H-C-H 107 deg), atoms as
+    {"symbol", "center" in bohr} — the geometry of tools/run_c20h42.py and of bench.py's real-molecule object (the
+    reference's own C20H42 input is not in the snapshot)."""
+    import math
+    ang = 1.0 / 0.52917724924
+    cc, ch, ccc, hch = 1.53, 1.09, math.radians(112.0), math.radians(107.0)
+    dx, dz = cc * math.sin(ccc / 2), cc * math.cos(ccc / 2)
+    atoms = []
+    Cs = [np.array([i * dx, 0.0, 0.5 * dz * (1 if i % 2 == 0 else -1)]) for i in range(nc)]
+    for c in Cs:
+        atoms.append(("C", c))
+    for i, c in enumerate(Cs):
+        up = 1.0 if i % 2 == 0 else -1.0                        # side of the zigzag this carbon sticks out to
+        hy, hz = ch * math.sin(hch / 2), ch * math.cos(hch / 2)
+        atoms.append(("H", c + np.array([0.0, hy, up * hz])))
+        atoms.append(("H", c + np.array([0.0, -hy, up * hz])))
+        if i in (0, nc - 1):                                     # methyl ends: third hydrogen continues the zigzag
+            sgn = -1.0 if i == 0 else 1.0
+            atoms.append(("H", c + ch * np.array([sgn * math.sin(ccc / 2), 0.0, -up * math.cos(ccc / 2)])))
+    return [{"symbol": sym, "center": list(map(float, r * ang))} for sym, r in atoms]

@@ -28,6 +28,24 @@ def test_bench_prints_the_contract_line():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0.3 < rf["frac"] < 1.0 and d["value"] > 50.0
+    # traffic is either a PMC record of exactly this kernel source and shape, or null with the reason
+    assert "traffic_source" in rf and (rf["traffic"] is None or rf["traffic"] > 0.5 * rf["alg_bytes_per_launch"])
+    # the Fock-build rate is quoted twice, labelled: useful flops (K symmetric, W on the kept pairs) and SURVEY 8d's dense formula
+    for k in ("fock_build_useful_tflops", "fock_build_useful_pct_fp64_mfma_peak", "fock_build_tflops_dense_formula",
+              "fock_build_pct_fp64_mfma_peak_dense_formula", "replicated_ms", "allreduce_ms", "fock_build_ms", "vendor_kernels_per_step"):
+        assert k in d, k
+    assert "fock_build_tflops" not in d and d["fock_build_useful_tflops"] < d["fock_build_tflops_dense_formula"]
+    assert d["allreduce_ms"] == 0.0 and abs(d["replicated_ms"] + d["fock_build_ms"] - d["ms_per_step"]) < 1e-9
+    # the strong-scaling workload of north_star ((H2O)50 shape) measured in the same run, never `value`
+    w50 = d["scaling_w50"]
+    for kind in ("screened_13pct", "dense_map"):
+        for k in ("value", "ms_per_step", "fock_build_ms", "allreduce_ms", "replicated_ms", "kernels_ms", "device_GB_rank0"):
+            assert k in w50[kind], (kind, k)
+    assert 0.11 < w50["screened_13pct"]["kept_pair_fraction"] < 0.16 and w50["dense_map"]["kept_pair_fraction"] == 1.0
+    assert w50["screened_13pct"]["device_GB_rank0"] < 0.4 * w50["dense_map"]["device_GB_rank0"]
+    assert w50["screened_13pct"]["kernels_ms"]["k_exchange_W"] < 0.3 * w50["dense_map"]["kernels_ms"]["k_exchange_W"]
+    # a real molecule through the same path beside the synthetic fixed point
+    assert d["real_molecule"].get("converged") is True, d["real_molecule"]
     # the optional spectral-projection density solver is reported beside, on the same problem, with the same energy
     assert d["density_solver"]["name"] == "eigh"
     assert d["alt"]["density_solver"] == "sp2" and d["alt"]["value"] > 50.0 and abs(d["alt"]["energy_minus_eigh"]) < 1e-6
@@ -38,6 +56,29 @@ def test_bench_cpu_baseline_object_shape():
     sys.path.insert(0, ROOT)
     import bench
     cb = bench.cpu_baseline(24, 40, 4, budget_s=0.5)
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "blas", "dense", "screened"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["blas"]["vendor"] and cb["blas"]["threads"] == cb["cores"] and any(k.startswith("dgemm_") for k in cb["blas"])
+    assert cb["dense"]["fock_build_s"] > 0 and cb["screened"]["fock_build_s"] > 0 and 0.3 < cb["screened"]["kept_pair_fraction"] < 0.6
+
+
+def test_cpu_baseline_port_matches_the_numpy_oracle():
+    """oracle/c/jcdf_cpu_baseline.c (the reference's two CPU modes on the host BLAS) against oracle/df_fock.py."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import cpu_baseline as cbm, df_fock as orc
+    from juliachem_jl_amd import synthetic
+    base = cbm.CpuBaseline(calibrate_n=256)
+    for (N, Q, o, kept) in [(60, 40, 7, None), (130, 50, 9, 0.4), (257, 48, 9, 0.3)]:
+        s = synthetic.make(N, Q, o, seed=3, kept_fraction=kept)
+        B = orc.calculate_B(s.J2c, s.T)
+        Co = s.C[:, :o]
+        ref = s.H + orc.df_rhf_fock_build_BLAS(B, Co)
+        F, _ = base.fock_dense(np.asfortranarray(B), Co, s.H)
+        assert np.abs(F - ref).max() < 1e-12 * np.abs(ref).max()
+        sd = orc.get_screening_metadata(s.mask if s.mask is not None else np.ones((N, N), bool))
+        Bp = orc.pack_three_center(B, sd)
+        ref2 = s.H + orc.df_rhf_fock_build_screened(Bp, Co, sd)
+        F2, _ = base.fock_screened(Bp, sd, Co, s.H)
+        assert np.abs(F2 - ref2).max() < 1e-12 * np.abs(ref2).max()

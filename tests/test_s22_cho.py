@@ -1,0 +1,80 @@
+"""north_star: "energies must match the reference CPU SCF to 1e-8 Eh on the S22 set".  The reference's own S22 test
+(test/runtests.jl:26-63) runs every complex from example_inputs/S22/NN_MP2.json in 6-31G(2df,p) (+ cc-pVTZ-JKFIT for
+the density-fitted run) and asserts  E_RHF ~ GAMESS  (:62, test/s22_gamess_values.json)  and  |E_RHF - E_DF| <= 1.5 mEh
+(:63).  The ten complexes made of C, H and O only (2, 3, 8, 9, 10, 11, 16, 17, 20, 22 — both benzene dimers, BASELINE
+config 2's molecule, among them) can be run here: the reference's logs hold the 6-31G(2df,p) / cc-pVTZ-JKFIT tables of
+exactly these three elements (tests/golden/*.json, extracted by oracle/make_water_golden.py; geometries and GAMESS
+energies by oracle/make_s22_golden.py).  N, S, ... tables are not in the snapshot: the other twelve complexes stay
+unpinned.
+
+Asserted per complex:
+  (a) |E_DF - E_GAMESS(RHF)| <= 1.5e-3 Eh   — the reference's own acceptance interval, chained from :62 and :63;
+  (b) |E_DF(device) - E_DF(CPU oracle)| <= 1e-8 Eh at convergence, same integrals (north_star's figure).
+Tolerances: (a) 1.5e-3 (runtests.jl:63); (b) 1e-8 Eh with dele 1e-9 / rmsd 1e-8."""
+import json
+import os
+
+import pytest
+
+import s22_case
+
+D, BASIS, AUX, CHARGES = s22_case.load()
+ORACLE = json.load(open(os.path.join(s22_case.GOLDEN, "s22_cho_oracle.json")))["energies"]
+KEYS = sorted(D["complexes"], key=int)
+SMALL = ["2", "8", "16"]             # re-derived by the CPU suite (seconds each)
+FLAGS = {"dele": 1e-9, "rmsd": 1e-8, "niter": 80}
+
+
+def _n_occ(atoms, c):
+    return (sum(CHARGES[a["symbol"]] for a in atoms) - c["molecular_charge"]) // 2
+
+
+def test_fixture_is_the_c_h_o_subset_of_s22():
+    assert KEYS == ["2", "3", "8", "9", "10", "11", "16", "17", "20", "22"]
+    for k in KEYS:
+        assert set(D["complexes"][k]["symbols"]) <= {"C", "H", "O"}
+        # every committed oracle energy lies inside the reference's own acceptance interval around GAMESS
+        assert abs(ORACLE[k]["energy"] - D["complexes"][k]["gamess_rhf_energy"]) <= D["df_tolerance_hartree"], k
+
+
+@pytest.mark.parametrize("key", SMALL)
+def test_oracle_reproduces_committed_energy_and_gamess(key):
+    """CPU: library host integrals + oracle SCF land on GAMESS within the reference's 1.5 mEh and on the committed
+    oracle energy (tests/golden/s22_cho_oracle.json) to 1e-9 — the fixture the GPU tests of the large complexes use
+    cannot go stale unnoticed."""
+    atoms, c = s22_case.atoms_of(D, key)
+    res, N, Q = s22_case.oracle_energy(atoms, BASIS, AUX, CHARGES, _n_occ(atoms, c))
+    assert res.converged
+    assert (N, Q) == (ORACLE[key]["N"], ORACLE[key]["Q"])
+    assert abs(res.energy - c["gamess_rhf_energy"]) <= D["df_tolerance_hartree"]
+    assert abs(res.energy - ORACLE[key]["energy"]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", KEYS)
+def test_s22_device_energy(key):
+    """GPU: rhf.run (host integrals -> device Cholesky -> B on the device -> HIP Fock build -> device SCF)."""
+    from juliachem_jl_amd import rhf
+    atoms, c = s22_case.atoms_of(D, key)
+    out = rhf.run(atoms, CHARGES, BASIS, AUX, dict(FLAGS), molecular_charge=c["molecular_charge"])
+    assert out["Converged?"]
+    E = out["Energy"]
+    assert abs(E - c["gamess_rhf_energy"]) <= D["df_tolerance_hartree"], (E, c["gamess_rhf_energy"])      # (a)
+    assert abs(E - ORACLE[key]["energy"]) <= 1e-8, (E, ORACLE[key]["energy"])                               # (b)
+    if key in ("2", "9"):            # (b) once more against an oracle run in this process, not the committed number
+        res, _, _ = s22_case.oracle_energy(atoms, BASIS, AUX, CHARGES, _n_occ(atoms, c))
+        assert abs(E - res.energy) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_s22_benzene_dimer_screened_path_and_sp2():
+    """Complex 20 (T-shaped benzene dimer) once more through the Schwarz-screened packed layout (df_use_adaptive off:
+    GPUDF.jl path instead of DenseGPUDF.jl) and with the spectral-projection density solver: same energy to 1e-8."""
+    from juliachem_jl_amd import rhf
+    atoms, c = s22_case.atoms_of(D, "20")
+    out = rhf.run(atoms, CHARGES, BASIS, AUX, dict(FLAGS, df_use_adaptive=False, density_solver="sp2"))
+    assert out["Converged?"]
+    assert out["Timings"].non_timing_data["contraction_algorithm"] == "screened hip"
+    # the screened algorithm drops pairs below the Schwarz threshold (df_sigma 1e-5): a real, tiny change of the energy
+    assert abs(out["Energy"] - ORACLE["20"]["energy"]) <= 2e-6
+    assert abs(out["Energy"] - c["gamess_rhf_energy"]) <= D["df_tolerance_hartree"]

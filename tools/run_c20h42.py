@@ -5,32 +5,13 @@ reference's S22 log (tests/golden/s22_10_benzene_methane_631g2dfp_jkfit.json; th
 are not in the snapshot) — DF-RHF on one MI355X through rhf.run: 956 AO, 3390 auxiliary functions, 81 occupied
 orbitals, Schwarz-screened packed layout.
 usage: python tools/run_c20h42.py [n_carbons] [density_solver]"""
-import json, math, os, sys, time
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from juliachem_jl_amd import rhf
 
-ANG = 1.0 / 0.52917724924
-
-
-def n_alkane(nc):
-    cc, ch, ccc, hch = 1.53, 1.09, math.radians(112.0), math.radians(107.0)
-    dx, dz = cc * math.sin(ccc / 2), cc * math.cos(ccc / 2)
-    atoms = []
-    C = [np.array([i * dx, 0.0, 0.5 * dz * (1 if i % 2 == 0 else -1)]) for i in range(nc)]
-    for i, c in enumerate(C):
-        atoms.append(("C", c))
-    for i, c in enumerate(C):
-        up = 1.0 if i % 2 == 0 else -1.0                        # side of the zigzag this carbon sticks out to
-        hy, hz = ch * math.sin(hch / 2), ch * math.cos(hch / 2)
-        atoms.append(("H", c + np.array([0.0, hy, up * hz])))
-        atoms.append(("H", c + np.array([0.0, -hy, up * hz])))
-        if i in (0, nc - 1):                                     # methyl ends: third hydrogen continues the zigzag
-            s = -1.0 if i == 0 else 1.0
-            atoms.append(("H", c + ch * np.array([s * math.sin(ccc / 2), 0.0, -up * math.cos(ccc / 2)])))
-    return [{"symbol": s, "center": list(map(float, r * ANG))} for s, r in atoms]
-
+from juliachem_jl_amd.synthetic import n_alkane
 
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 solver = sys.argv[2] if len(sys.argv) > 2 else "eigh"
