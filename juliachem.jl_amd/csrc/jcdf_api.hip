@@ -49,6 +49,7 @@ struct jcdf_handle {
     int64_t N = 0, Qtot = 0, q0 = 0, q1 = 0, Ql = 0, o = 0, P = 0;
     int64_t Np = 0, ldq = 0, Wld = 0, Plow = 0;
     int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_qt = 0, vld = 0;
+    int w_rem = 0;                      // trailing orbitals (n_occ mod 16) contracted by VALU FMAs in the DMA W kernel
     int n_chunks = 0, n_stages = 0;
     int w_ablate = 0;                  // timing-only ablation bits of the DMA kernel (JCDF_W_ABLATE; never set in production)
     bool w_skip_partial = true;        // DMA kernel: waves past the end of the aux rows (partial last tile) issue no MFMA
@@ -180,10 +181,38 @@ hipError_t launch_W_ablate_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     return hipSuccess;
 }
 
+// VALU remainder forms: WM full MFMA row tiles + REM trailing orbitals
+template <int WM, int REM>
+hipError_t launch_W_rem_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
+{
+    using D = WDmaCfg<WM, 1, 2, REM>;
+    if (set_attr_only)
+        return hipFuncSetAttribute((const void *)k_exchange_W_dma<WM, 1, 2, 0, REM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   D::SMEM_BYTES);
+    const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
+    hipLaunchKernelGGL((k_exchange_W_dma<WM, 1, 2, 0, REM>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
+                       h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+    return hipSuccess;
+}
+
+template <int WM>
+hipError_t launch_W_rem(jcdf_handle *h, hipStream_t st, bool attr)
+{
+    switch (h->w_rem) {
+        case 1: return launch_W_rem_t<WM, 1>(h, st, attr);
+        case 2: return launch_W_rem_t<WM, 2>(h, st, attr);
+        default: return launch_W_rem_t<WM, 3>(h, st, attr);
+    }
+}
+
 template <int WM, int WVM>
 hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
     using Cfg = WCfg<WM, WVM>;
+    if (h->w_dma && h->w_rem) {
+        if constexpr (WVM == 1 && WM >= 3 && WM <= 7) return launch_W_rem<WM>(h, st, set_attr_only);
+    }
     if (h->w_dma) {
         if constexpr (WVM == 1 && WM <= 6) {
             if (h->tq == 256) return launch_W_dma_t<WM, WVM, 4>(h, st, set_attr_only);
@@ -277,8 +306,10 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 255) / 256)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
                            (int)h->Ql, (int)h->ldq, h->dV);
         // incl. all padding: orbitals to opad, K_p to whole stages, the aux index to whole 32-column wave tiles (DMA kernel)
-        r.flops = 2.0 * (double)h->kcw * (double)h->n_stages * (double)h->opad *
-                  (h->w_dma && h->w_skip_partial ? (double)roundup(h->ldq, h->tq / 4) : (double)h->n_qt * h->tq);
+        r.flops = 2.0 * (double)h->kcw * (double)h->n_stages *
+                  ((double)(h->opad - (h->w_rem ? 16 : 0)) *
+                       (h->w_dma && h->w_skip_partial ? (double)roundup(h->ldq, h->tq / 4) : (double)h->n_qt * h->tq) +
+                   (double)h->w_rem * (double)h->n_qt * h->tq);               // MFMA row tiles + the VALU remainder orbitals
         r.alg_flops = 2.0 * Ql * P * o + 2.0 * Ql * N * o;           // the reference's 2 Q P o (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * P + 8.0 * Ql * o * N;               // B read once + W written once
         ok(hipEventRecord(r.e1, st));
@@ -765,17 +796,26 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     if ((size_t)h->ldq * 8 > 150 * 1024) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: aux shard too long for the Coulomb kernel's LDS copy of V (use more shards)");
     // orbital (M) tiling of the W kernel: up to 128 orbitals -> one 4-wave workgroup holds them all;
     // more -> 8-wave workgroups of up to 256 orbitals (two wave rows share the staged B tile)
+    h->w_rem = 0;
     if (n_occ <= 128 || getenv("JCDF_W_NO_WVM2")) {
         h->WVMw = 1;
         h->n_mtiles = (int)((n_occ + 127) / 128);
         h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
+        // 1..3 orbitals past the last full MFMA row tile: VALU FMAs instead of a 16-row tile of padding (DMA kernel,
+        // 48 <= n_occ <= 115; C20H42: 81 = 5 x 16 + 1).  JCDF_W_REM=0 pads as before.
+        const char *e = getenv("JCDF_W_REM"), *d = getenv("JCDF_W_DMA");
+        const int64_t r = n_occ % 16;
+        if (!(e && atoi(e) == 0) && !(d && atoi(d) == 0) && h->n_mtiles == 1 && r >= 1 && r <= 3 && n_occ / 16 >= 3 && n_occ / 16 <= 7) {
+            h->w_rem = (int)r;
+            h->WMw = (int)(n_occ / 16);
+        }
     } else {
         h->WVMw = 2;
         h->n_mtiles = (int)((n_occ + 255) / 256);
         h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 31) / 32);    // per wave row
         if (h->WMw < 5) h->WMw = 5;
     }
-    h->opad = h->n_mtiles * h->WVMw * h->WMw * 16;
+    h->opad = h->n_mtiles * h->WVMw * h->WMw * 16 + (h->w_rem ? 16 : 0);
     {
         const char *e = getenv("JCDF_W_DMA");
         h->w_dma = !(e && atoi(e) == 0);

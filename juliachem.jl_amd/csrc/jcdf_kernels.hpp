@@ -41,7 +41,7 @@ __global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int
     const int q = (int)(idx / opad), i = (int)(idx % opad);
     const double v = (q < N && i < o) ? C[q + (int64_t)N * i] : 0.0;
     Cpad[idx] = v;
-    if (q >= N) return;
+    if (q >= N || i >= 16 * WM * rows_per_p) return;      // trailing orbitals of the VALU remainder path are not in Cv
     const int wrow = i / (16 * WM), il = i % (16 * WM);       // wrow = mt*WVM + wm < rows_per_p
     const int m = il >> 4, g = il & 3, j = (il & 15) >> 2;
     Cv[(((int64_t)q * rows_per_p + wrow) * 4 + g) * (4 * WM) + 4 * m + j] = v;
@@ -275,19 +275,24 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // WN = 16-column MFMA tiles per wave along the aux index: 2 (aux tile 128) or 4 (aux tile 256: every staged C row
 // feeds twice as many MFMAs — up to 96 orbitals the kernel is bound by the bytes it moves into LDS, half of which
 // are C rows, not by MFMA issue: skipping 5 % of the MFMAs did not change its time).
-template <int WM, int WVM, int WN>
+// REM = 1..3 trailing orbitals (n_occ mod 16) that do not fill an MFMA row tile are contracted by VALU FMAs from the
+// same LDS stage instead of being padded to 16 MFMA rows: C20H42 has 81 occupied orbitals = 5 MFMA tiles + 1 (a 6th
+// tile would be 15/16 padding, a sixth of the kernel's MFMA work).
+template <int WM, int WVM, int WN, int REM = 0>
 struct WDmaCfg {
-    static constexpr int TM = 16 * WM * WVM, TN = 64 * WN;
-    static constexpr int AH = (TM <= 128) ? 1 : 2;                  // 1 KB pieces per C row
+    static constexpr int TM = 16 * WM * WVM, TN = 64 * WN;          // MFMA rows
+    static constexpr int TMA = TM + (REM ? 16 : 0);                 // staged orbitals of a C row
+    static_assert(REM == 0 || (WVM == 1 && WN == 2 && TMA <= 128), "VALU remainder: 4-wave form only");
+    static constexpr int AH = (TMA <= 128) ? 1 : 2;                 // 1 KB pieces per C row
     static constexpr int BH = TN / 128;                             // 1 KB pieces per B row
     // LDS row strides (doubles): >= the row, and = 16 mod 32 (conflict-free ds_read_b64 across the 4 k rows of an MFMA step)
-    static constexpr int LDAS = ((TM + 15) / 32) * 32 + 16, LDBS = TN + 16;
+    static constexpr int LDAS = ((TMA + 15) / 32) * 32 + 16, LDBS = TN + 16;
     // up to 96 orbitals the 128-wide form fits 3 workgroups per CU (<= 168 VGPRs, 3 x 48 KB of LDS with a ring of 3)
     static constexpr bool THREE = JCDF_W_DMA_WAVES3 && WVM == 1 && WM <= 6 && WN == 2;
     static constexpr int RING = (THREE || WN == 4) ? 3 : 4;
     static constexpr int WAVES_PER_SIMD = THREE ? 3 : 2;
     static constexpr int STAGE_DOUBLES = KCD * (LDAS + LDBS);
-    static constexpr int SMEM_BYTES = RING * STAGE_DOUBLES * 8;
+    static constexpr int SMEM_BYTES = (RING * STAGE_DOUBLES + (REM ? 128 : 0)) * 8;
     static constexpr int NW = 4 * WVM, NT = 64 * NW;
     static constexpr int A_PER = KCD * AH / NW, B_PER = KCD * BH / NW;   // pieces per wave and stage
     static constexpr int G = A_PER + B_PER;
@@ -305,15 +310,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // with them; they are template bits because a run-time flag around the DMA issue or the wait de-pipelines the loop:
 // the same kernel took 5.05 instead of 1.70 ms): 2 = no DMA after the prologue, 4 = no wait / barrier in the loop,
 // 8 = no W stores, 16 = no MFMA.
-template <int WM, int WVM, int WN, int ABL = 0>
-__global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) void k_exchange_W_dma(
+template <int WM, int WVM, int WN, int ABL = 0, int REM = 0>
+__global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN, REM>::WAVES_PER_SIMD)) void k_exchange_W_dma(
     const double *__restrict__ Bp, int64_t ldq, const double *__restrict__ Cpad, const double *__restrict__ Cv,
     double *__restrict__ Wt, int64_t Wld, double *__restrict__ vpart, int vld, int o, int opad, int n_mt, int n_qt,
     const int *__restrict__ wchunk, const int *__restrict__ stg_c, const int *__restrict__ stg_q,
     const int *__restrict__ stg_p, int skip_partial)
 {
-    using D = WDmaCfg<WM, WVM, WN>;
-    constexpr int TM = D::TM, TN = D::TN, LDAS = D::LDAS, LDBS = D::LDBS, NW = D::NW, AH = D::AH, BH = D::BH;
+    using D = WDmaCfg<WM, WVM, WN, REM>;
+    constexpr int TM = D::TM, TMA = D::TMA, TN = D::TN, LDAS = D::LDAS, LDBS = D::LDBS, NW = D::NW, AH = D::AH, BH = D::BH;
     constexpr int A_PER = D::A_PER, B_PER = D::B_PER, G = D::G, RING = D::RING;
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
@@ -338,6 +343,10 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
     // a wave whose aux columns all lie past the end of the rows (last, partial aux tile) issues no MFMA and no
     // store; it still moves its DMA pieces and meets every barrier
     const bool active = !skip_partial || qt * TN + wn * (16 * WN) < ldq;
+    // VALU remainder: thread tid < 128 owns aux column tid of the tile for the REM trailing orbitals
+    double racc[REM ? REM : 1], rv = 0.0;
+#pragma unroll
+    for (int r = 0; r < (REM ? REM : 1); ++r) racc[r] = 0.0;
     const double *Ag = Cpad + mt * TM + 2 * lane;
     const double *Bg = Bp + (int64_t)qt * TN + 2 * lane;
 
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
         for (int i = 0; i < A_PER; ++i) {
             const int s = wave + i * NW, row = s / AH, half = s % AH;
             // lanes past the row's orbitals are masked off: their 16 bytes would land in the next LDS row
-            if (TM % 128 == 0 || half * 64 + lane < TM / 2)
+            if (TMA % 128 == 0 || half * 64 + lane < TMA / 2)
                 __builtin_amdgcn_global_load_lds((glb_void_t *)(Ag + (int64_t)iq[i] * opad + half * 128),
                                                  (lds_void_t *)(As + row * LDAS + half * 128), 16, 0, 0);
         }
@@ -389,6 +398,20 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[n], acc[m][n], 0, 0, 0);
                     }
                 }
+        }
+    };
+    auto compute_rem = [&](int buf) {               // waves 0 and 1: one aux column per thread, all KCD rows of the stage
+        if constexpr (REM > 0) {
+            if (wave < 2) {
+                const double *Ar = smem + buf * D::STAGE_DOUBLES + TM;
+                const double *Br = smem + buf * D::STAGE_DOUBLES + KCD * LDAS + tid;
+#pragma unroll
+                for (int k = 0; k < KCD; ++k) {
+                    const double bk = Br[k * LDBS];
+#pragma unroll
+                    for (int r = 0; r < REM; ++r) racc[r] += Ar[k * LDAS + r] * bk;
+                }
+            }
         }
     };
     const int qcol = qt * TN + wn * (16 * WN) + lr;         // aux column of acc[.][0]; acc[.][n] is 16 n further
@@ -431,6 +454,22 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
             for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
     };
 
+    auto epilogue_rem = [&](int p) {                 // trailing orbitals: W[p][(TM + r, Q)] and their share of V
+        if constexpr (REM > 0) {
+            if (wave < 2) {
+                const int Qc = qt * TN + tid;
+                const double *cp = Cpad + (int64_t)p * opad + mt * TM + TM;
+#pragma unroll
+                for (int r = 0; r < REM; ++r) {
+                    rv += racc[r] * cp[r];
+                    const int64_t k = (int64_t)(mt * TM + TM + r) * ldq + Qc;
+                    if (Qc < ldq) Wt[(((int64_t)(p >> 7) * (Wld >> 4) + (k >> 4)) * 128 + (p & 127)) * 16 + (k & 15)] = racc[r];
+                    racc[r] = 0.0;
+                }
+            }
+        }
+    };
+
     // prologue: stages 0 .. RING-2 in flight, stage 0 retired
     constexpr int AHEAD = RING - 1;                  // the DMA of stage t + AHEAD is issued at the start of phase t
     constexpr int FLY = (AHEAD - 1) * G;             // pieces that stay in flight across a barrier
@@ -446,8 +485,10 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
     for (int t = 0; t < nst; ++t) {
         if constexpr (!(ABL & 2)) issue(nxt);        // -> the buffer phase t-1 has finished reading
         compute_stage(cur);
+        compute_rem(cur);
         const int p = stg_p[t0 + t];
         next_idx(t + AHEAD + 1);
+        if (p >= 0) epilogue_rem(p);
         if (p >= 0 && active) {
             epilogue(p);
             // behind stage t+1's pieces the counter now holds FLY pieces and this wave's W stores
@@ -476,6 +517,16 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN>::WAVES_PER_SIMD)) 
         if (wm == 0) {
 #pragma unroll
             for (int n = 0; n < WN; ++n) vacc[n] += smem[wn * (16 * WN) + 16 * n + lr];
+        }
+    }
+    if constexpr (REM > 0) {                         // the remainder's share of V, column by column, through the scratch row
+        double *scr = smem + RING * D::STAGE_DOUBLES;
+        __builtin_amdgcn_s_barrier();
+        if (wave < 2) scr[tid] = rv;
+        __syncthreads();
+        if (lk == 0) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n) vacc[n] += scr[wn * (16 * WN) + 16 * n + lr];
         }
     }
     if (wm == 0 && lk == 0) {

@@ -26,6 +26,31 @@ def _candidates():
     return out
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota where one is set (a
+    GPU box of the pool shows all of the host's hardware threads in the mask but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.999)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, (q + per - 1) // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+# numpy's OpenBLAS is compiled for at most 64 threads (its thread-metadata table overflows beyond: heap corruption)
+MAX_THREADS = {0: 1 << 30, 1: 64}
+
+
 class CpuBaseline:
     def __init__(self, threads=None, calibrate_n=4096):
         self.lib = C.CDLL(LIB)
@@ -35,21 +60,22 @@ class CpuBaseline:
         self.lib.jcbl_dgemm_calibration.argtypes = [_I64, C.c_int, C.c_int]
         self.lib.jcbl_fock_dense.argtypes = [_I64, _I64, _I64, _P, _P, _P, _P, _P, C.c_int]
         self.lib.jcbl_fock_screened.argtypes = [_I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int]
-        self.threads = int(threads or len(os.sched_getaffinity(0)))
+        want = int(threads or host_cores())
         self.calibration = {}
         best = None
         for path, kind in _candidates():
             if self.lib.jcbl_load_blas(path.encode(), kind) != 0:
                 continue
             name = self.lib.jcbl_blas_name().decode()
-            gf = float(self.lib.jcbl_dgemm_calibration(calibrate_n, 2, self.threads))
-            self.calibration[name] = gf
+            nthr = min(want, MAX_THREADS[kind])
+            gf = float(self.lib.jcbl_dgemm_calibration(calibrate_n, 2, nthr))
+            self.calibration[name] = {"gflops": gf, "threads": nthr}
             if best is None or gf > best[2]:
-                best = (path, kind, gf, name)
+                best = (path, kind, gf, name, nthr)
         if best is None:
             raise OSError("no host BLAS could be loaded (looked for libmkl_rt and numpy's OpenBLAS)")
         assert self.lib.jcbl_load_blas(best[0].encode(), best[1]) == 0
-        self.blas, self.dgemm_gflops, self.calibrate_n = best[3], best[2], calibrate_n
+        self.blas, self.dgemm_gflops, self.calibrate_n, self.threads = best[3], best[2], calibrate_n, best[4]
 
     def fock_dense(self, B, C_occ, H):
         """B (Q, N, N) Fortran order, C_occ (N, o), H (N, N) -> (F, times{density,V,J,W,K})"""

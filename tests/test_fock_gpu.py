@@ -25,7 +25,10 @@ def _handle(N, Qtot, q0, q1, o, pq=None):
 
 
 # sizes chosen to hit every padding edge: N % 16, N % 128, o % 16, Q % 16, tiny, > one tile
-SHAPES = [(7, 11, 2), (25, 96, 5), (37, 50, 3), (128, 64, 16), (130, 100, 17), (255, 80, 33), (300, 96, 81)]
+# (o = 49, 50, 81, 83, 115: 1..3 orbitals past the last full MFMA row tile are contracted by VALU FMAs in the W kernel;
+#  o = 116 is the first count past that rule; Q = 130, 260: partial last aux tile of the 128-wide W tiles)
+SHAPES = [(7, 11, 2), (25, 96, 5), (37, 50, 3), (128, 64, 16), (130, 100, 17), (255, 80, 33), (300, 96, 81),
+          (140, 130, 49), (150, 40, 50), (190, 260, 83), (160, 48, 115), (160, 33, 116)]
 
 
 @pytest.mark.parametrize("N,Q,o", SHAPES)
