@@ -303,7 +303,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_exchange_W", st, ok);
         ok(launch_W(h, st));
         const int nparts = h->n_chunks * h->n_mtiles;
-        hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 255) / 256)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
+        hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 31) / 32)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
                            (int)h->Ql, (int)h->ldq, h->dV);
         // incl. all padding: orbitals to opad, K_p to whole stages, the aux index to whole 32-column wave tiles (DMA kernel)
         r.flops = 2.0 * (double)h->kcw * (double)h->n_stages *

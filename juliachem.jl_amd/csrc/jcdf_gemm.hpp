@@ -1,13 +1,10 @@
-// jcdf_gemm.hpp — fp64 MFMA "TN" GEMM core for gfx950 (MI355X), shared by the
-// three MFMA kernels of the DF Fock build (W, K, metric-apply).
+// jcdf_gemm.hpp — fp64 MFMA GEMM cores for gfx950 (MI355X).
 //
-//   acc[m][n] += sum_k A[k][m] * B[k][n]
-//
-// Both operands are stored k-major (row k contiguous in m resp. n).  Every
-// matrix on the path is laid out so that this holds (see DESIGN.md "layout"):
-//   W pass   : A = C_occ  [q][i]      B = B_Q   [q][p]
-//   K pass   : A = W      [(Q,i)][p]  B = W     [(Q,i)][p']
-//   metric   : A = Linv^T [s][r]      B = T     [s][(q,p)]
+// "TN" core (first half of this file):   acc[m][n] += sum_k A[k][m] * B[k][n]
+// Both operands are stored k-major (row k contiguous in m resp. n):
+//   W pass (register-staged form)   : A = C_occ [q][i]        B = Bp [(q,p)][Q]   (rows gathered per stage)
+//   Cholesky / D&C / SP2 helpers    : see jcdf_chol.hpp, jcdf_dc.hpp, jcdf_sp2.hpp
+// "NT" core (second half): both operands k-contiguous — the K pass and the metric apply.
 //
 // Hardware mapping (CDNA4): v_mfma_f64_16x16x4_f64, one f64 of A and of B per
 // lane: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]; the
@@ -180,17 +177,22 @@ __device__ __forceinline__ void gemm_tn_core(const double *__restrict__ Ag, int6
 //
 //   acc[m][n] += sum_k A[m][k] * B[n][k]
 //
-//   K pass  : A = Wt [p ][(i,Q)]     B = Wt   [p'][(i,Q)]   (SYRK over the packed exchange intermediate)
+//   K pass  : A = Wb [p ][(i,Q)]     B = Wb   [p'][(i,Q)]   (SYRK over the blocked exchange intermediate)
 //   metric  : A = T  [c ][s]         B = Linv [r ][s]       (B = L^-1 T in the reference's (Q_d, P) layout)
 //
-// A stage is TM (resp. TN) rows x KC contiguous doubles (one 128-B line per row for KC = 16);
-// every thread moves 16 B along k.  The LDS image keeps the global orientation, rows padded to
-// KC + 2 doubles: the 32 lanes of a ds_read_b64 group (16 rows x 2 k) then hit 32 different
-// bank pairs ((row * (KC+2) + k) mod 32 is a bijection for KC = 16 and 32), stores are 16-B aligned.
+// A stage is TM (resp. TN) rows x KC = 16 contiguous doubles (one 128-B line per row); every thread moves 16 B
+// along k.  The LDS image keeps the global orientation with UNPADDED 128-B rows and an XOR swizzle inside the row:
+// double k of row r sits at position  (((k >> 1) ^ (r & 7)) << 1) | ((k & 1) ^ ((r >> 3) & 1)),  i.e. the 16-B chunk
+// index is XOR-ed with the low row bits and the two halves of a chunk swap for rows 8..15 of every 16.  The 16 lanes of
+// an MFMA operand read (16 rows, one k) then cover all banks in the 32-bank mode of ds_read2_b64 and in the 64-bank
+// mode of ds_read_b64; the stores stay whole 16-B chunks (ds_write_b128).  (Rows padded to 18 doubles instead: 41 % of
+// the K kernel's LDS cycles were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT 4.6e7 of SQ_LDS_IDX_ACTIVE 1.1e8 — rows
+// r and r + 8 share their banks when the compiler pairs the reads into ds_read2_b64.)
 template <class Cfg>
 struct GemmNT {
     static constexpr int KC = Cfg::KC, TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
-    static constexpr int LDK = KC + 2;
+    static_assert(KC == 16, "the swizzle is written for 16-double rows");
+    static constexpr int LDK = KC;
     static constexpr int STAGE_DOUBLES = (TM + TN) * LDK;
     static constexpr int SMEM_BYTES = 2 * STAGE_DOUBLES * 8;
     static constexpr int A_VEC = TM * KC / 2, B_VEC = TN * KC / 2;
@@ -200,7 +202,7 @@ struct GemmNT {
 
 // Ag -> A[m0][k0], Bg -> B[n0][k0]; lda/ldb = row strides in doubles (even); nchunks = K / KC.
 // STREAM_A: the A operand is read once from HBM by the whole grid (non-temporal loads).
-// SAME: the A and B tiles are the same rows (diagonal tile of a SYRK): B is neither loaded nor staged.
+// same: the A and B tiles are the same rows (diagonal tile of a SYRK): B is neither loaded nor staged.
 // BLOCKED: the operands are stored in blocks of (tile rows x KC) (chunk t of a tile is one contiguous block, lda/ldb = KC):
 // consecutive chunks are TM*KC (resp. TN*KC) doubles apart.
 // mfma_on = false: this wave issues no MFMA (its accumulators are not needed: upper block of a diagonal SYRK tile);
@@ -232,32 +234,44 @@ __device__ __forceinline__ void gemm_nt_core(const double *__restrict__ Ag, int6
                 rb[i] = *reinterpret_cast<const double2_t *>(Bg + (int64_t)r * ldb + (int64_t)chunk * (BLOCKED ? Cfg::TN * KC : KC) + 2 * c);
             }
     };
+    // chunk c of row r -> chunk c ^ (r & 7), halves swapped when bit 3 of r is set
+    auto store_one = [&](double *base, int r, int c, double2_t v) {
+        if (r & 8) v = double2_t{v.y, v.x};
+        *reinterpret_cast<double2_t *>(base + r * LDK + 2 * (c ^ (r & 7))) = v;
+    };
     auto store_stage = [&](int buf) {
         double *As = smem + buf * G::STAGE_DOUBLES;
         double *Bs = As + Cfg::TM * LDK;
 #pragma unroll
         for (int i = 0; i < G::A_PER_THREAD; ++i) {
-            const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
-            *reinterpret_cast<double2_t *>(As + r * LDK + 2 * c) = ra[i];
+            const int idx = tid + i * NT;
+            store_one(As, idx / (KC / 2), idx % (KC / 2), ra[i]);
         }
         if (!same)
 #pragma unroll
             for (int i = 0; i < G::B_PER_THREAD; ++i) {
-                const int idx = tid + i * NT, r = idx / (KC / 2), c = idx % (KC / 2);
-                *reinterpret_cast<double2_t *>(Bs + r * LDK + 2 * c) = rb[i];
+                const int idx = tid + i * NT;
+                store_one(Bs, idx / (KC / 2), idx % (KC / 2), rb[i]);
             }
     };
+    // position of k = 4 ks + lk in this lane's rows (all rows of a lane have the same low 4 bits, lr)
+    int koff[KC / 4];
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+        const int k = 4 * ks + lk;
+        koff[ks] = (((k >> 1) ^ (lr & 7)) << 1) | ((k & 1) ^ ((lr >> 3) & 1));
+    }
     auto compute_stage = [&](int buf) {
         if (!mfma_on) return;
-        const double *As = smem + buf * G::STAGE_DOUBLES + (wm * (WM * 16) + lr) * LDK + lk;
-        const double *Bs = smem + buf * G::STAGE_DOUBLES + (same ? 0 : Cfg::TM * LDK) + (wn * (WN * 16) + lr) * LDK + lk;
+        const double *As = smem + buf * G::STAGE_DOUBLES + (wm * (WM * 16) + lr) * LDK;
+        const double *Bs = smem + buf * G::STAGE_DOUBLES + (same ? 0 : Cfg::TM * LDK) + (wn * (WN * 16) + lr) * LDK;
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             double a[WM], b[WN];
 #pragma unroll
-            for (int m = 0; m < WM; ++m) a[m] = As[m * 16 * LDK + ks * 4];
+            for (int m = 0; m < WM; ++m) a[m] = As[m * 16 * LDK + koff[ks]];
 #pragma unroll
-            for (int n = 0; n < WN; ++n) b[n] = Bs[n * 16 * LDK + ks * 4];
+            for (int n = 0; n < WN; ++n) b[n] = Bs[n * 16 * LDK + koff[ks]];
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll

@@ -537,14 +537,27 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN, REM>::WAVES_PER_SI
 }
 
 // V[Q] = sum over the W kernel's partials, fixed order; entries Ql <= Q < ldq are set to 0.
-__global__ void k_reduce_V(const double *__restrict__ vpart, int nparts, int vld, int Ql, int ldq, double *__restrict__ V)
+// 32 aux columns x 8 slices of the partials per workgroup (one thread per column and slice, slices added in fixed order
+// through LDS): with one thread per column walking all ~200-500 partial rows alone the launch took 55-60 us.
+__global__ __launch_bounds__(256) void k_reduce_V(const double *__restrict__ vpart, int nparts, int vld, int Ql, int ldq,
+                                                  double *__restrict__ V)
 {
-    const int Q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (Q >= ldq) return;
+    __shared__ double part[8][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int Q = blockIdx.x * 32 + col;
     double v = 0.0;
-    if (Q < Ql)
-        for (int t = 0; t < nparts; ++t) v += vpart[(int64_t)t * vld + Q];
-    V[Q] = v;
+    if (Q < Ql) {
+        const int per = (nparts + 7) / 8, t0 = sl * per, t1 = min(nparts, t0 + per);
+        for (int t = t0; t < t1; ++t) v += vpart[(int64_t)t * vld + Q];
+    }
+    part[sl][col] = v;
+    __syncthreads();
+    if (sl == 0 && Q < ldq) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += part[k][col];
+        V[Q] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------
