@@ -123,3 +123,17 @@ def test_cpu_modes_are_refused():
     with pytest.raises(jc.JCDFError):
         jc.df_rhf_fock_build(sd, None, None, bs, np.eye(2), 1, jc.SCFOptions(contraction_mode="screened"),
                              np.eye(2), jc.create_jctiming())
+
+
+def test_julia_glue_writes_every_timing_key_of_the_reference_operator():
+    """julia/JCDFHip.jl (the ccall glue of INTEGRATION.md; Julia is not in the image, so this is a text check): every
+    JCTiming key df_rhf_fock_build_GPU! writes (GPUDF.jl:280-301) is written by df_rhf_fock_build_HIP! too — the
+    reference's timing-analysis scripts read them."""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "JCDFHip.jl")).read()
+    for key in ("GPU_W_time", "GPU_V_time", "GPU_J_time", "GPU_K_time", "GPU_density_time", "gpu_fock_time",
+                "GPU_non_zero_coeff_time", "gpu_copy_J_time", "gpu_copy_sym_time", "GPU_H_add_time",
+                "fock_gpu_cpu_copy_reduce_time", "total_fock_gpu_time"):
+        assert "JCTC.%s" % key in src, key
+    for key in ("K_time", "W_time", "V_time", "J_time", "fock_time"):
+        assert "JCTiming_key(JCTC.%s, iteration)" % key in src, key
