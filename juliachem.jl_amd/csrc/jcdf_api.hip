@@ -231,7 +231,8 @@ hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 
 hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
-    if (h->w_ablate && h->w_dma && h->WVMw == 1 && h->WMw == 6 && h->tq == TILE_Q) {
+    // (the ablation forms exist for 6 MFMA row tiles without the VALU remainder: C20H42 shape with JCDF_W_REM=0)
+    if (h->w_ablate && h->w_dma && !h->w_rem && h->WVMw == 1 && h->WMw == 6 && h->tq == TILE_Q) {
         switch (h->w_ablate) {
             case 2: return launch_W_ablate_t<2>(h, st, attr);
             case 4: return launch_W_ablate_t<4>(h, st, attr);

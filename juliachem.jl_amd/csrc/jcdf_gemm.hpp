@@ -46,7 +46,7 @@ struct GemmCfg {
 // nchunks = K / KC.  All tile loads must be in bounds (buffers are padded).
 // STREAM_B: the B operand is read exactly once from HBM by the whole grid (the
 // 3-index tensor) -> non-temporal loads keep it from evicting the reused operand.
-// ABL: timing-only ablation bits for tools/w_ablate.hip (0 in the product):
+// ABL: timing-only ablation bits (0 in the product; round 1's tools/w_ablate.hip, profiles/r01_w_ablate.txt):
 //   1 = no A global loads after the first stage, 2 = no B global loads after the first
 //   stage, 4 = no LDS re-staging (ds_write) after the first stage, 8 = no barrier in the loop.
 // PREFETCH = 2: two register sets, every global load has two compute phases to land (for the
