@@ -251,6 +251,22 @@ int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_
                         int32_t iterations, void *d_work, int64_t work_bytes, double *d_info);
 
 
+/* Small dense products of the device-resident SCF iteration on the library's own fp64 MFMA cores (csrc/jcdf_blas.hpp), so
+ * that an iteration issues no vendor BLAS kernel (reference: BLAS.symm!/gemm! at SCF.jl:473-481, 1080-1108).  Row-major
+ * device matrices; M, N multiples of 32 (zero padded), leading dimensions even.
+ *   _tn:  C[m][n] = alpha sum_k A[k][m] B[k][n]   (K multiple of 32; for symmetric A: C = alpha A B)
+ *   _nt:  C[m][n] = sum_k A[m][k] B[n][k]         (K multiple of 16; the eigensolver's back-transformation U = Q Z) */
+int32_t jcdf_gemm_tn_device(void *stream, int64_t M, int64_t N, int64_t K, double alpha, const double *d_A, int64_t lda,
+                            const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
+int32_t jcdf_gemm_nt_device(void *stream, int64_t M, int64_t N, int64_t K, const double *d_A, int64_t lda, const double *d_B,
+                            int64_t ldb, double *d_C, int64_t ldc);
+/* DIIS history bookkeeping on the device (EnergyHelpers.jl:234-258, SCF.jl:473-488): e = T^T - T for T = S D F (leading
+ * dimension ld) packed n x n into d_e_slot, F into d_f_slot; the new row of Pulay dot products <e_s, e_head> for all nd
+ * slots (each of length len); and the extrapolated F = sum_s coef[s] F_s written back with leading dimension ld. */
+int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double *d_T, const double *d_F, double *d_e_slot, double *d_f_slot);
+int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots);
+int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F);
+
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */
 int64_t jcdf_device_bytes(const jcdf_handle *h);

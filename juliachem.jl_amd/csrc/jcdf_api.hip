@@ -11,6 +11,7 @@
 #include "jcdf_dc.hpp"
 #include "jcdf_sp2.hpp"
 #include "jcdf_scf.hpp"
+#include "jcdf_blas.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -657,6 +658,8 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_trsm_small, (128 * 129 + 128 * 17) * 8);
     set((const void *)k_dc_update_mfma, DcCfg::SMEM_BYTES);
     set((const void *)k_dc_prepare, 64 * 1024);
+    set((const void *)k_blas_gemm_tn, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_blas_gemm_nt, GemmNT<BlasNTCfg>::SMEM_BYTES);
     return first;
 }
 
@@ -1463,6 +1466,56 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         std::swap(lda, ldn);
         std::swap(wa, wn);
     }
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+// ---- small dense products of the device SCF iteration (jcdf_blas.hpp) -------------------------------------------
+int32_t jcdf_gemm_tn_device(void *stream, int64_t M, int64_t N, int64_t K, double alpha, const double *d_A, int64_t lda,
+                            const double *d_B, int64_t ldb, double *d_C, int64_t ldc)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32 || K % 32 || !d_A || !d_B || !d_C || lda < M || ldb < N || ldc < N ||
+        (lda & 1) || (ldb & 1))
+        return JCDF_ERR_INVALID;
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    const int n_tn = (int)(N / 32);
+    hipLaunchKernelGGL(k_blas_gemm_tn, dim3((unsigned)((M / 32) * n_tn)), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, (hipStream_t)stream,
+                       d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 32), alpha, n_tn);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_gemm_nt_device(void *stream, int64_t M, int64_t N, int64_t K, const double *d_A, int64_t lda, const double *d_B,
+                            int64_t ldb, double *d_C, int64_t ldc)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32 || K % 16 || !d_A || !d_B || !d_C || lda < K || ldb < K || ldc < N ||
+        (lda & 1) || (ldb & 1))
+        return JCDF_ERR_INVALID;
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    const int n_tn = (int)(N / 32);
+    hipLaunchKernelGGL(k_blas_gemm_nt, dim3((unsigned)((M / 32) * n_tn)), dim3(BlasNTCfg::NT), GemmNT<BlasNTCfg>::SMEM_BYTES,
+                       (hipStream_t)stream, d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 16), n_tn);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double *d_T, const double *d_F, double *d_e_slot, double *d_f_slot)
+{
+    if (n <= 0 || ld < n || !d_T || !d_F || !d_e_slot || !d_f_slot) return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_diis_push, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_T, d_F, ld, (int)n, d_e_slot,
+                       d_f_slot);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots)
+{
+    if (nd < 1 || nd > 64 || head < 0 || head >= nd || len <= 0 || !d_e_hist || !d_dots) return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_diis_dots, dim3((unsigned)nd), dim3(1024), 0, (hipStream_t)stream, d_e_hist, len, (int)head, d_dots);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F)
+{
+    if (nd < 1 || nd > 64 || n <= 0 || ld < n || !d_f_hist || !d_coef || !d_F) return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_diis_mix, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_f_hist, n * n, (int)nd, d_coef,
+                       (int)n, d_F, ld);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

@@ -31,6 +31,7 @@ _OP_NONE = 111                # rocblas_operation_none
 class DeviceEigh:
     def __init__(self, n: int, device: torch.device):
         self.n, self.device = n, device
+        self.U_padded = None
         self.ok = False
         self.calls = self.fallbacks = 0
         try:
@@ -53,6 +54,12 @@ class DeviceEigh:
             self.wb = wb
             self.with_q = n <= int(self.lib.jcdf_sytrd_max_n(1)) and not os.environ.get("JCDF_EIGH_ORMTR")
             self.Q = torch.empty((n, n), **f64) if self.with_q else None
+            # back-transformation U = Q Z on the library's NT MFMA core: operands with a leading dimension that is a
+            # multiple of 32 and zero padding (jcdf_gemm_nt_device); Zt[j][k] = Z[k][j] is what stedc writes with ldz = npad
+            self.npad = (n + 31) // 32 * 32
+            self.Qp = torch.zeros((self.npad, self.npad), **f64) if self.with_q else None
+            self.Zt = torch.zeros((self.npad, self.npad), **f64)
+            self.Up = torch.zeros((self.npad, self.npad), **f64)
             self.own_stedc = not os.environ.get("JCDF_EIGH_VENDOR_STEDC")
             if self.own_stedc:
                 self.dc_wb = int(self.lib.jcdf_stedc_workspace_bytes(n))
@@ -67,6 +74,7 @@ class DeviceEigh:
         """Fp: symmetric (n, n) device tensor.  Returns (eigenvalues ascending, U with
         eigenvectors in columns), like torch.linalg.eigh."""
         self.calls += 1
+        self.U_padded = None                                      # set when U was produced zero padded (npad x npad) by the library
         if not self.ok:                                           # counted in `fallbacks` when the switch happened; see `reason`
             return torch.linalg.eigh(Fp)
         n = self.n
@@ -76,12 +84,22 @@ class DeviceEigh:
         p = lambda t: C.c_void_p(t.data_ptr())
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
                                           p(self.Q) if self.with_q else None, p(self.work), self.wb)
+        own_gemm = self.with_q and self.own_stedc
         if rc == 0 and self.own_stedc:
-            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(self.Cm), n, p(self.dc_work),
+            zt, ldz = (self.Zt, self.npad) if own_gemm else (self.Cm, n)
+            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(zt), ldz, p(self.dc_work),
                                             self.dc_wb)
         elif rc == 0:
             rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
                                           p(self.info))
+        if rc == 0 and own_gemm:
+            # U[m][j] = sum_k Q[m][k] Z[k][j] = sum_k Qp[m][k] Zt[j][k]: the NT core; U comes back zero padded (npad x npad)
+            self.Qp[:n, :n].copy_(self.Q)
+            rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), self.npad, self.npad, self.npad, p(self.Qp), self.npad, p(self.Zt),
+                                              self.npad, p(self.Up), self.npad)
+            if rc == 0:
+                self.U_padded = self.Up
+                return self.D, self.Up[:n, :n]
         if rc == 0 and self.with_q:
             # Cm holds Z column-major == Z^T as a row-major tensor; Q is row-major: U = Q Z
             return self.D, self.Q @ self.Cm.T

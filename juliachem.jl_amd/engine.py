@@ -181,8 +181,10 @@ class DeviceFockBuilder:
 
 
 class DeviceSCF:
-    """SCF iteration with all matrices on the device (hcore guess, DIIS, damping;
-    SURVEY Appendix D).  Matrices are symmetric, so row/column-major coincide."""
+    """SCF iteration with all matrices on the device (hcore guess, DIIS, damping).  Matrices are
+    symmetric, so row/column-major coincide.  Every dense product of an iteration runs on the library's own fp64 MFMA
+    cores (`jcdf_gemm_tn_device` / `_nt_`, csrc/jcdf_blas.hpp): the N x N matrices live zero padded in (Np x Np)
+    buffers, Np = N rounded up to 32; `F`, `D`, `C` are the unpadded views."""
 
     def __init__(self, fb: DeviceFockBuilder, H: np.ndarray, S: np.ndarray, E_nuc: float, ndiis: int = 10,
                  density_solver: Optional[str] = None):
@@ -193,11 +195,16 @@ class DeviceSCF:
         self.fb = fb
         dev = fb.device
         self.N, self.n_occ = fb.N, fb.n_occ
-        self.H = torch.as_tensor(H, dtype=torch.float64, device=dev)
-        self.S = torch.as_tensor(S, dtype=torch.float64, device=dev)
-        s, U = torch.linalg.eigh(self.S)
+        self.Np = (self.N + 31) // 32 * 32
+        self.op = (self.n_occ + 31) // 32 * 32
+        from . import _lib
+        self._lib = _lib.load()
+        self._f64 = dict(dtype=torch.float64, device=dev)
+        self.Hp = self._padded(H)
+        self.Sp = self._padded(S)
+        s, U = torch.linalg.eigh(self.Sp[:self.N, :self.N])          # once per SCF (setup): vendor eigensolver
         keep = s >= 1.0e-6                                          # SCF.jl:142-162
-        self.X = (U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T
+        self.Xp = self._padded((U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T)
         self.E_nuc = E_nuc
         self.ndiis = ndiis
         self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM
@@ -209,45 +216,100 @@ class DeviceSCF:
             from .eigh import DeviceSP2
             self.sp2 = DeviceSP2(self.N, self.n_occ, dev)
         self.sp2_pivot = None
-        self.tail_work = torch.zeros(256, dtype=torch.float64, device=dev)
-        self.tail_out = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.tail_work = torch.zeros(256, **self._f64)
+        self.tail_out = torch.zeros(8, **self._f64)
         self.sp2_steps = self.sp2_fallbacks = 0
         self.sp2_two_pass = True
         self.sp2_reasons = {}
         self.sp2_skip = True                     # first step, and while the density still changes wholesale: eigensolver
         self.canonical = True                    # self.C / self.eps are the eigenvectors / eigenvalues of self.F
-        from . import _lib
-        self._lib = _lib.load()
         self.diis_on_host = bool(os.environ.get("JCDF_DIIS_HOST")) or self.ndiis > 15
+        # work matrices of the products (padded, zero outside N x N by construction of their factors)
+        self.T1 = torch.zeros((self.Np, self.Np), **self._f64)
+        self.T2 = torch.zeros((self.Np, self.Np), **self._f64)
+        self.Fpr = torch.zeros((self.Np, self.Np), **self._f64)     # X F X
+        self.Up = torch.zeros((self.Np, self.Np), **self._f64)      # eigenvectors of X F X (columns), padded
+        self.Ctp = torch.zeros((self.Np, self.Np), **self._f64)     # (X U)^T: row i = orbital i in the AO basis
+        self.Cop = torch.zeros((self.op, self.Np), **self._f64)     # occupied rows of it, zero rows up to a multiple of 32
+        self.Dp = torch.zeros((self.Np, self.Np), **self._f64)
         self.reset()
+
+    # ---- plumbing --------------------------------------------------------------------------------------------
+    def _padded(self, M) -> torch.Tensor:
+        out = torch.zeros((self.Np, self.Np), **self._f64)
+        out[:self.N, :self.N].copy_(torch.as_tensor(M, **self._f64))
+        return out
+
+    def _st(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.Hp.device).cuda_stream)
+
+    def _gemm_tn(self, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+        """out[m][n] = alpha sum_k A[k][m] B[k][n] on the library's MFMA core (A symmetric: out = alpha A B)."""
+        K, M = A.shape
+        N = B.shape[1]
+        rc = self._lib.jcdf_gemm_tn_device(self._st(), M, N, K, alpha, ctypes.c_void_p(A.data_ptr()), A.stride(0),
+                                           ctypes.c_void_p(B.data_ptr()), B.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0))
+        if rc != 0:
+            raise RuntimeError("jcdf_gemm_tn_device failed (status %d)" % rc)
+        return out
+
+    @property
+    def F(self) -> torch.Tensor:
+        return self.Fp_[:self.N, :self.N]
+
+    @property
+    def D(self) -> torch.Tensor:
+        return self.Dp[:self.N, :self.N]
+
+    @property
+    def C(self) -> torch.Tensor:
+        """MO coefficients, columns = orbitals (view of the transposed buffer the products leave)"""
+        return self.Ctp[:self.N, :self.N].t()
+
+    @property
+    def H(self) -> torch.Tensor:
+        return self.Hp[:self.N, :self.N]
+
+    @property
+    def S(self) -> torch.Tensor:
+        return self.Sp[:self.N, :self.N]
+
+    @property
+    def X(self) -> torch.Tensor:
+        return self.Xp[:self.N, :self.N]
 
     def reset(self) -> None:
         self.sp2_skip = True
-        self.F = self.H.clone()
-        self.D = torch.zeros_like(self.H)
+        self.Fp_ = self.Hp.clone()
+        self.Dp.zero_()
+        self.D_old = torch.zeros_like(self.Dp)
         self._checked_diag()                                       # "iteration 0", SCF.jl:178-181
-        self.F_old = self.F.clone()
+        self.F_old = self.Fp_.clone()
         self.E_old, self.dE, self.B_dim, self.iter = 0.0, 1.0, 1, 1
         # DIIS history: ring buffers on the device (slot of the newest entry = head); the small
-        # Pulay matrix lives on the host and gets ONE new row of dot products per iteration
+        # Pulay matrix is solved on the device and gets ONE new row of dot products per iteration
         nd = max(self.ndiis, 1)
-        self.e_hist = torch.zeros((nd, self.N * self.N), dtype=torch.float64, device=self.H.device)
-        self.F_hist = torch.zeros((nd, self.N * self.N), dtype=torch.float64, device=self.H.device)
+        self.e_hist = torch.zeros((nd, self.N * self.N), **self._f64)
+        self.F_hist = torch.zeros((nd, self.N * self.N), **self._f64)
         self.head, self.n_hist = -1, 0
         self.Bmat = np.zeros((nd, nd))
-        self.Bmat_d = torch.zeros((nd, nd), dtype=torch.float64, device=self.H.device)
-        self.coef_d = torch.zeros(nd, dtype=torch.float64, device=self.H.device)
-        self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.H.device)
+        self.Bmat_d = torch.zeros((nd, nd), **self._f64)
+        self.coef_d = torch.zeros(nd, **self._f64)
+        self.dots_d = torch.zeros(nd, **self._f64)
+        self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.Hp.device)
         self.trail: List[Tuple[int, float, float, float]] = []
 
     def _diag(self, use_sp2: bool = False) -> None:
         """SCF.jl:1072-1125: F' = X F X, eigh, C = X U, D = 2 C_o C_o^T (the energy: _tail)."""
-        Fp = self.X @ self.F @ self.X
+        N, o = self.N, self.n_occ
+        self._gemm_tn(self.Fp_, self.Xp, self.T1)                   # F X      (F symmetric)
+        self._gemm_tn(self.Xp, self.T1, self.Fpr)                   # X (F X)
         if use_sp2:
             # occupied-space projector P of F' by spectral projection; orthonormal basis of its range from the previous
             # occupied orbitals Cp (orthogonal basis): Y = P Cp, Y^T Y = L L^T, Cp_new^T = L^-1 Y^T, so that
-            # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (checked through the pivots)
-            P = self.sp2(Fp)
+            # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (checked through the pivots).
+            # (optional path: its two thin products and the Gram matrix go through torch)
+            P = self.sp2(self.Fpr[:N, :N])
             Yt = self.Cp_t @ P                                      # (o, N) = (P Cp)^T
             Cp_t, pivot = self._orthonormalise(Yt)
             if self.sp2_two_pass:
@@ -255,16 +317,22 @@ class DeviceSCF:
                 # ill-conditioned and one Cholesky pass leaves Cp orthonormal only to cond * eps — second pass (CholQR2)
                 Cp_t, _ = self._orthonormalise(Cp_t)
             self.Cp_t = Cp_t
-            self.Co_t = self.Cp_t @ self.X                          # (o, N): rows = occupied orbitals in the AO basis
+            self.Cop[:o, :N].copy_(self.Cp_t @ self.X)              # (o, N): rows = occupied orbitals in the AO basis
             self.sp2_pivot = pivot
             self.canonical = False
         else:
-            self.eps, U = self.eigh(Fp)
-            self.C = self.X @ U
-            self.Cp_t = U[:, :self.n_occ].T.contiguous()            # occupied orbitals in the orthogonal basis, (o, N)
-            self.Co_t = self.C[:, :self.n_occ].T.contiguous()       # (o, N) row-major == (N, o) column-major
+            self.eps, U = self.eigh(self.Fpr[:N, :N])
+            Up = self.eigh.U_padded                                 # the library path leaves U zero padded (Np x Np) already
+            if Up is None:
+                self.Up[:N, :N].copy_(U)
+                Up = self.Up
+            self._gemm_tn(Up, self.Xp, self.Ctp)                    # (X U)^T[i][m] = sum_k U[k][i] X[k][m]
+            if self.sp2 is not None:
+                self.Cp_t = Up[:N, :o].t().contiguous()             # occupied orbitals in the orthogonal basis, (o, N)
+            self.Cop[:o].copy_(self.Ctp[:o])
             self.canonical = True
-        self.D = 2.0 * (self.Co_t.T @ self.Co_t)
+        self.Co_t = self.Cop[:o, :N].contiguous()                   # (o, N) row-major == (N, o) column-major, for the Fock build
+        self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)             # D = 2 Co^T Co (zero rows of Cop add nothing)
 
     def _checked_diag(self) -> None:
         """Eigensolve whose status is read at once (one host sync): used where no scf tail follows — iteration 0 and
@@ -294,8 +362,7 @@ class DeviceSCF:
             L = torch.empty((o, o), dtype=torch.float64, device=Yt.device)
             piv = torch.empty(1, dtype=torch.float64, device=Yt.device)
             p = lambda t: ctypes.c_void_p(t.data_ptr())
-            rc = self._lib.jcdf_orthonormalise_rows_device(ctypes.c_void_p(torch.cuda.current_stream(Yt.device).cuda_stream), o,
-                                                           Yt.shape[1], p(G), p(Yt), p(Z), p(L), p(piv))
+            rc = self._lib.jcdf_orthonormalise_rows_device(self._st(), o, Yt.shape[1], p(G), p(Yt), p(Z), p(L), p(piv))
             if rc != 0:
                 raise RuntimeError("jcdf_orthonormalise_rows_device failed (status %d)" % rc)
             return Z, piv
@@ -304,13 +371,13 @@ class DeviceSCF:
 
     def _tail(self, D_old: torch.Tensor, use_sp2: bool) -> List[float]:
         """E_elec, ||D - D_old|| and the iteration's status words in one 64-byte record (`jcdf_scf_tail_device`), read
-        with ONE device-to-host copy — the only host synchronisation of the iteration."""
+        with ONE device-to-host copy — the only host synchronisation of the iteration.  (The padded buffers are summed
+        whole: the padding is zero in all four.)"""
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         err, info = self.eigh.status_tensors()
-        rc = self._lib.jcdf_scf_tail_device(ctypes.c_void_p(torch.cuda.current_stream(self.H.device).cuda_stream), self.N,
-                                            p(self.D), p(D_old), p(self.F), p(self.H), p(self.diis_flag), p(err), p(info),
-                                            p(self.sp2.info) if use_sp2 else None, p(self.sp2_pivot) if use_sp2 else None,
-                                            p(self.tail_work), p(self.tail_out))
+        rc = self._lib.jcdf_scf_tail_device(self._st(), self.Np, p(self.Dp), p(D_old), p(self.Fp_), p(self.Hp), p(self.diis_flag),
+                                            p(err), p(info), p(self.sp2.info) if use_sp2 else None,
+                                            p(self.sp2_pivot) if use_sp2 else None, p(self.tail_work), p(self.tail_out))
         if rc != 0:
             raise RuntimeError("jcdf_scf_tail_device failed (status %d)" % rc)
         if self.fb.world > 1:
@@ -333,9 +400,9 @@ class DeviceSCF:
         """Eigenvectors / eigenvalues of the current Fock matrix into self.C / self.eps (what the reference has after
         every iteration; with density_solver = "sp2" only on request)."""
         if not self.canonical:
-            D = self.D
+            D = self.Dp.clone()
             self._checked_diag()                                   # sets C, eps (and D, Co_t: the same space)
-            self.D = D
+            self.Dp.copy_(D)
 
     profile = False
 
@@ -356,41 +423,43 @@ class DeviceSCF:
             self._t = time.perf_counter()
             if not hasattr(self, "seg"):
                 self.seg = {}
-        F = self.fb.build(self.Co_t).clone()                       # SCF.jl:463
+        N = self.N
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        Fb = torch.zeros((self.Np, self.Np), **self._f64) if self.Np != N else None
+        Fnew = self.fb.build(self.Co_t)                            # SCF.jl:463 (N x N, contiguous)
+        if Fb is None:
+            Fp = Fnew.clone()
+        else:
+            Fb[:N, :N].copy_(Fnew)
+            Fp = Fb
         self._mark("fock")
-        if self.ndiis > 0 and not self.diis_on_host:               # SCF.jl:472-501, the Pulay system solved on the device
+        if self.ndiis > 0:                                         # SCF.jl:472-501
             nd = self.ndiis
-            FDS = (F @ self.D) @ self.S
-            e = (FDS - FDS.T).reshape(-1)
+            self._gemm_tn(self.Dp, Fp, self.T1)                     # D F
+            self._gemm_tn(self.Sp, self.T1, self.T2)                # S D F = (F D S)^T
             self.head = (self.head + 1) % nd
             self.n_hist = min(self.n_hist + 1, nd)
-            self.e_hist[self.head].copy_(e)
-            self.F_hist[self.head].copy_(F.reshape(-1))
-            dots = self.e_hist @ e                                 # <e_slot, e_new> for every slot: one GEMV, stays on the device
+            rc = self._lib.jcdf_diis_push_device(self._st(), N, self.Np, p(self.T2), p(Fp), p(self.e_hist[self.head]),
+                                                 p(self.F_hist[self.head]))
+            rc = rc or self._lib.jcdf_diis_dots_device(self._st(), nd, self.head, N * N, p(self.e_hist), p(self.dots_d))
+            if rc != 0:
+                raise RuntimeError("DIIS history kernels failed (status %d)" % rc)
             solve = self.iter > 1
+        if self.ndiis > 0 and not self.diis_on_host:               # the Pulay system solved on the device
             if solve:
                 self.B_dim = min(self.B_dim + 1, nd)
-            rc = self._lib.jcdf_diis_device(ctypes.c_void_p(torch.cuda.current_stream(F.device).cuda_stream), nd, self.head,
-                                            self.B_dim if solve else 1, 1 if solve else 0,
-                                            ctypes.c_void_p(self.Bmat_d.data_ptr()), ctypes.c_void_p(dots.data_ptr()),
-                                            ctypes.c_void_p(self.coef_d.data_ptr()), ctypes.c_void_p(self.diis_flag.data_ptr()))
+            rc = self._lib.jcdf_diis_device(self._st(), nd, self.head, self.B_dim if solve else 1, 1 if solve else 0,
+                                            p(self.Bmat_d), p(self.dots_d), p(self.coef_d), p(self.diis_flag))
+            if rc == 0 and solve:
+                # sum_k c_k F_k; a faulty system leaves the unit vector on the newest F
+                rc = self._lib.jcdf_diis_mix_device(self._st(), nd, N, self.Np, p(self.F_hist), p(self.coef_d), p(Fp))
             if rc != 0:
-                raise RuntimeError("jcdf_diis_device failed (status %d)" % rc)
-            if solve:
-                # sum_k c_k F_k as a GEMV on the transposed view; a faulty system leaves the unit vector on the newest F
-                F = torch.mv(self.F_hist.t(), self.coef_d).reshape(self.N, self.N)
+                raise RuntimeError("jcdf_diis_device / _mix failed (status %d)" % rc)
         elif self.ndiis > 0:                                       # host solve (JCDF_DIIS_HOST=1): one extra sync per iteration
-            nd = self.ndiis
-            FDS = (F @ self.D) @ self.S
-            e = (FDS - FDS.T).reshape(-1)
-            self.head = (self.head + 1) % nd
-            self.n_hist = min(self.n_hist + 1, nd)
-            self.e_hist[self.head].copy_(e)
-            self.F_hist[self.head].copy_(F.reshape(-1))
-            dots = (self.e_hist @ e).cpu().numpy()                 # <e_slot, e_new> for every slot: one GEMV + one 80-B D2H
+            dots = self.dots_d.cpu().numpy()
             self.Bmat[self.head, :] = dots
             self.Bmat[:, self.head] = dots
-            if self.iter > 1:
+            if solve:
                 self.B_dim = min(self.B_dim + 1, nd)
                 n = self.B_dim
                 order = [(self.head - k) % nd for k in range(n)]   # newest first, like the reference's vcat
@@ -405,17 +474,20 @@ class DeviceSCF:
                         raise np.linalg.LinAlgError("non-finite DIIS coefficients")
                     cfull = np.zeros(nd)
                     cfull[order] = c
-                    # sum_k c_k F_k as a GEMV on the transposed view (rocBLAS runs the (1 x nd)(nd x N^2) product as a 55 us GEMM)
-                    F = torch.mv(self.F_hist.t(), torch.as_tensor(cfull, device=F.device)).reshape(self.N, self.N)
+                    self.coef_d.copy_(torch.as_tensor(cfull, device=self.coef_d.device))
+                    rc = self._lib.jcdf_diis_mix_device(self._st(), nd, N, self.Np, p(self.F_hist), p(self.coef_d), p(Fp))
+                    if rc != 0:
+                        raise RuntimeError("jcdf_diis_mix_device failed (status %d)" % rc)
                 except np.linalg.LinAlgError:                      # "Faulty DIIS!" SCF.jl:493-499
                     self.B_dim = 2
         self._mark("diis")
         x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
         if x != 1.0:
-            F = (1.0 - x) * self.F_old + x * F
-        self.F = F.contiguous()
-        self.F_old = self.F.clone()
-        D_old = self.D
+            Fp = (1.0 - x) * self.F_old + x * Fp
+        self.Fp_ = Fp
+        self.F_old = self.Fp_.clone()
+        self.D_old.copy_(self.Dp)
+        D_old = self.D_old
         self._mark("damp")
         use_sp2 = self.sp2 is not None and not self.sp2_skip
         self._diag(use_sp2)
