@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--config", default="C20H42")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-w50", action="store_true", help="skip the scaling_w50 object")
+    ap.add_argument("--no-real", action="store_true", help="skip the real_molecule object (profiling runs)")
     ap.add_argument("--density-solver", default="eigh", choices=["eigh", "sp2"],
                     help="eigh: the reference's eigensolve per iteration (default, what `value` is quoted on); sp2: spectral projection")
     args = ap.parse_args()
@@ -377,8 +378,10 @@ def main():
             "fock_build_ms": fock_ms,
             "allreduce_ms": coll_ms,
             "replicated_ms": ms - fock_ms - coll_ms,          # DIIS + damping + X F X + eigensolve + density + energy (per rank, not sharded)
-            "vendor_kernels_per_step": "X F X (2), F D S (2), D = 2 Co^T Co (1), Q Z (1), X U (1) as rocBLAS GEMMs + 2 GEMVs of the DIIS "
-                                       "history through torch; every other launch of a step is the library's own",
+            "vendor_kernels_per_step": 0,                     # default path: every GEMM / GEMV of a step runs on the library's own cores
+            "vendor_kernels_note": "X F X, S D F, (X U)^T, D = 2 Co^T Co, U = Q Z: jcdf_gemm_tn/nt_device; DIIS history: jcdf_diis_*_device; "
+                                   "torch launches left in a step are copies / fills / one axpy. The optional sp2 solver (alt) still "
+                                   "issues 4 thin rocBLAS products per step",
             # useful = what must be executed (K symmetric, W on the kept pairs); dense_formula = SURVEY 8d's F_alg (K counted twice over)
             "fock_build_useful_tflops": f_use / (fock_ms * 1e-3) / 1e12,
             "fock_build_useful_pct_fp64_mfma_peak": 100.0 * f_use / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
@@ -399,7 +402,7 @@ def main():
                                         "note": "stand-alone launch after the timed loop; in the timed steps J overlaps K (kernels_ms)"}},
             "scaling_w50": w50,
         }
-        if world == 1:
+        if world == 1 and not args.no_real:
             out["real_molecule"] = real_molecule()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, Q, o)

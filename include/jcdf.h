@@ -264,7 +264,8 @@ int32_t jcdf_gemm_nt_device(void *stream, int64_t M, int64_t N, int64_t K, const
  * dimension ld) packed n x n into d_e_slot, F into d_f_slot; the new row of Pulay dot products <e_s, e_head> for all nd
  * slots (each of length len); and the extrapolated F = sum_s coef[s] F_s written back with leading dimension ld. */
 int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double *d_T, const double *d_F, double *d_e_slot, double *d_f_slot);
-int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots);
+int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots,
+                              double *d_work /* 64 * nd doubles */);
 int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F);
 
 /* ---- introspection ------------------------------------------------------------ */

@@ -74,7 +74,7 @@ PROTOTYPES = {
     "jcdf_gemm_tn_device": (C.c_int32, [_P, _I64, _I64, _I64, C.c_double, _P, _I64, _P, _I64, _P, _I64]),
     "jcdf_gemm_nt_device": (C.c_int32, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64]),
     "jcdf_diis_push_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P]),
-    "jcdf_diis_dots_device": (C.c_int32, [_P, C.c_int32, C.c_int32, _I64, _P, _P]),
+    "jcdf_diis_dots_device": (C.c_int32, [_P, C.c_int32, C.c_int32, _I64, _P, _P, _P]),
     "jcdf_diis_mix_device": (C.c_int32, [_P, C.c_int32, _I64, _I64, _P, _P, _P]),
     "jcdf_device_bytes": (_I64, [_P]),
     "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),

@@ -1504,10 +1504,12 @@ int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double 
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
-int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots)
+int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots, double *d_work)
 {
-    if (nd < 1 || nd > 64 || head < 0 || head >= nd || len <= 0 || !d_e_hist || !d_dots) return JCDF_ERR_INVALID;
-    hipLaunchKernelGGL(k_diis_dots, dim3((unsigned)nd), dim3(1024), 0, (hipStream_t)stream, d_e_hist, len, (int)head, d_dots);
+    if (nd < 1 || nd > 64 || head < 0 || head >= nd || len <= 0 || !d_e_hist || !d_dots || !d_work) return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_diis_dots_partial, dim3(DIIS_DOT_PARTS, (unsigned)nd), dim3(256), 0, (hipStream_t)stream, d_e_hist, len, (int)head,
+                       d_work);
+    hipLaunchKernelGGL(k_diis_dots_final, dim3(1), dim3(64), 0, (hipStream_t)stream, d_work, (int)nd, d_dots);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

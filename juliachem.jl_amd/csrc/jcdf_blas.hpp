@@ -59,20 +59,34 @@ __global__ __launch_bounds__(256) void k_diis_push(const double *__restrict__ T,
     f_slot[idx] = F[(int64_t)r * ld + c];
 }
 
-// dots[s] = <e_hist[s], e_hist[head]>, one workgroup per slot, fixed summation order
-__global__ __launch_bounds__(1024) void k_diis_dots(const double *__restrict__ e_hist, int64_t len, int head, double *__restrict__ dots)
+// dots[s] = <e_hist[s], e_hist[head]>: DIIS_DOT_PARTS workgroups per slot leave partial sums, a second launch adds them
+// in fixed order (one workgroup per slot alone took 260 us at N = 510: 10 workgroups on a 256-CU chip).
+constexpr int DIIS_DOT_PARTS = 64;
+__global__ __launch_bounds__(256) void k_diis_dots_partial(const double *__restrict__ e_hist, int64_t len, int head,
+                                                           double *__restrict__ part)
 {
-    __shared__ double red[1024];
-    const double *a = e_hist + (int64_t)blockIdx.x * len, *b = e_hist + (int64_t)head * len;
+    __shared__ double red[256];
+    const int s_ = blockIdx.y;
+    const double *a = e_hist + (int64_t)s_ * len, *b = e_hist + (int64_t)head * len;
+    const int64_t per = (len + DIIS_DOT_PARTS - 1) / DIIS_DOT_PARTS, i0 = blockIdx.x * per, i1 = min(len, i0 + per);
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < len; i += 1024) s += a[i] * b[i];
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) s += a[i] * b[i];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int h = 512; h > 0; h >>= 1) {
+    for (int h = 128; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) dots[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) part[s_ * DIIS_DOT_PARTS + blockIdx.x] = red[0];
+}
+
+__global__ void k_diis_dots_final(const double *__restrict__ part, int nd, double *__restrict__ dots)
+{
+    const int s_ = threadIdx.x;
+    if (s_ >= nd) return;
+    double s = 0.0;
+    for (int k = 0; k < DIIS_DOT_PARTS; ++k) s += part[s_ * DIIS_DOT_PARTS + k];
+    dots[s_] = s;
 }
 
 // F[r][c] (ld) = sum_s coef[s] F_hist[s][r*n + c]  (slots with coef 0 are skipped: unused history)

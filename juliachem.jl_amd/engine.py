@@ -296,6 +296,7 @@ class DeviceSCF:
         self.Bmat_d = torch.zeros((nd, nd), **self._f64)
         self.coef_d = torch.zeros(nd, **self._f64)
         self.dots_d = torch.zeros(nd, **self._f64)
+        self.dots_work = torch.zeros(64 * nd, **self._f64)
         self.diis_flag = torch.zeros(1, dtype=torch.int32, device=self.Hp.device)
         self.trail: List[Tuple[int, float, float, float]] = []
 
@@ -441,7 +442,7 @@ class DeviceSCF:
             self.n_hist = min(self.n_hist + 1, nd)
             rc = self._lib.jcdf_diis_push_device(self._st(), N, self.Np, p(self.T2), p(Fp), p(self.e_hist[self.head]),
                                                  p(self.F_hist[self.head]))
-            rc = rc or self._lib.jcdf_diis_dots_device(self._st(), nd, self.head, N * N, p(self.e_hist), p(self.dots_d))
+            rc = rc or self._lib.jcdf_diis_dots_device(self._st(), nd, self.head, N * N, p(self.e_hist), p(self.dots_d), p(self.dots_work))
             if rc != 0:
                 raise RuntimeError("DIIS history kernels failed (status %d)" % rc)
             solve = self.iter > 1

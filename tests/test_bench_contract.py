@@ -34,6 +34,7 @@ def test_bench_prints_the_contract_line():
     for k in ("fock_build_useful_tflops", "fock_build_useful_pct_fp64_mfma_peak", "fock_build_tflops_dense_formula",
               "fock_build_pct_fp64_mfma_peak_dense_formula", "replicated_ms", "allreduce_ms", "fock_build_ms", "vendor_kernels_per_step"):
         assert k in d, k
+    assert d["vendor_kernels_per_step"] == 0
     assert "fock_build_tflops" not in d and d["fock_build_useful_tflops"] < d["fock_build_tflops_dense_formula"]
     assert d["allreduce_ms"] == 0.0 and abs(d["replicated_ms"] + d["fock_build_ms"] - d["ms_per_step"]) < 1e-9
     # the strong-scaling workload of north_star ((H2O)50 shape) measured in the same run, never `value`

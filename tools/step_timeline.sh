@@ -2,7 +2,7 @@
 # Kernel timeline of one SCF step of the bench (run on the GPU box through gpurun): tools/step_timeline.sh [eigh|sp2]
 cd /tmp && export TMPDIR=/tmp
 S=${1:-eigh}
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/timeline_$S -o a -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --density-solver $S --steps 20 > $GRAFT_REPO_ROOT/gpurun_out/timeline_$S.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/timeline_$S -o a -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --density-solver $S --steps 20 --no-w50 --no-real > $GRAFT_REPO_ROOT/gpurun_out/timeline_$S.log 2>&1
 python3 - $GRAFT_REPO_ROOT/gpurun_out/timeline_$S <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/*kernel_trace.csv')[0]
