@@ -94,6 +94,7 @@ namespace {
     } while (0)
 
 hipError_t ensure_device_attributes();
+constexpr int K_DMA_SMEM_BYTES = 2 * 2 * 128 * KC * 8;      // two buffers x (A block + B block)
 
 int32_t fail(jcdf_handle *h, int32_t code, const std::string &msg)
 {
@@ -329,8 +330,13 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     auto run_K = [&](size_t slot) {
         KernelRec &r = rec_begin(h, slot, "k_exchange_K", st, ok);
         const int nblk = (int)(roundup(h->S, 8) * h->ntri);
-        hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), GemmNT<KCfg4>::SMEM_BYTES, st, h->dWt,
-                           h->Wld, h->ntri, h->S, h->KS, h->dKslab);
+        static const bool k_dma = [] { const char *e = getenv("JCDF_K_DMA"); return !(e && atoi(e) == 0); }();
+        if (k_dma)
+            hipLaunchKernelGGL(k_exchange_K_dma<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), K_DMA_SMEM_BYTES, st, h->dWt, h->Wld,
+                               h->ntri, h->S, h->KS, h->dKslab);
+        else
+            hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), GemmNT<KCfg4>::SMEM_BYTES, st, h->dWt,
+                               h->Wld, h->ntri, h->S, h->KS, h->dKslab);
         const double nT = (double)(h->Np / TILE_P);
         // diagonal tiles: the wave that owns the upper 64 x 64 block issues no MFMA
         r.flops = 2.0 * ((double)h->ntri - 0.25 * nT) * 128.0 * 128.0 * (double)h->S * (double)h->KS;
@@ -649,6 +655,7 @@ hipError_t set_device_kernel_attributes()
         if (first == hipSuccess && e != hipSuccess) first = e;
     };
     set((const void *)k_exchange_K<KCfg4>, GemmNT<KCfg4>::SMEM_BYTES);
+    set((const void *)k_exchange_K_dma<KCfg4>, K_DMA_SMEM_BYTES);
     set((const void *)k_metric_apply, GemmNT<MCfg>::SMEM_BYTES);
     set((const void *)k_coulomb_J, 150 * 1024);
     set((const void *)k_chol_diag, CHOL_DIAG_LDS);

@@ -25,6 +25,8 @@ namespace jcdf {
 constexpr int KC = 16;          // k rows per LDS stage
 constexpr int TILE_P = 128;     // p-tile of the K kernel == padding unit of Np
 constexpr int TILE_Q = 128;     // aux-index tile of the W kernel
+typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // ---------------------------------------------------------------------------
 // C_occ (N x o, column-major, reference layout DensityFitting.jl:49) -> Cpad, Cv.
@@ -266,8 +268,6 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
 // ds_write, no branch around a load; the stage table has 8-slot granularity (K_p rounded up to 8 instead of 16).
 // ---------------------------------------------------------------------------
 constexpr int KCD = 8;
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
 
 #ifndef JCDF_W_DMA_WAVES3
 #define JCDF_W_DMA_WAVES3 1
@@ -681,6 +681,105 @@ __global__ __launch_bounds__(Cfg::NT, (Cfg::NT == 256) ? 2 : 1) void k_exchange_
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 out[tile_row<Cfg>(m, j) * Cfg::TN + tile_col<Cfg>(n)] = acc[m][n][j];
+}
+
+// The same SYRK with LDS-DMA staging: an operand stage IS one contiguous 16 KB block of Wb, so 16 wave instructions of
+// 1 KB copy it into LDS — with the 16-B chunks of every row XOR-swizzled by the low row bits ON THE SOURCE SIDE (the
+// DMA's LDS side is lane-linear): chunk c of row r lands at chunk position c ^ (r & 7).  (A plain copy makes the 16
+// rows of an operand read hit two banks, 8-way conflicts: 35 instead of 60 TF.)  What is left is the 2-way conflict
+// of rows r and r + 8, 16 LDS cycles per k step against 1024 MFMA cycles.  Two LDS buffers: the DMA of stage t+1 is issued at the start of
+// phase t into the buffer phase t-1 has finished reading and has the whole phase (64 MFMAs per wave) to land; operands
+// come from L2.  No staging registers, no ds_write, no address arithmetic in the loop beyond one pointer increment.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void k_exchange_K_dma(const double *__restrict__ Wt, int64_t Wld, int ntri, int S, int KS,
+                                                               double *__restrict__ Kslab)
+{
+    static_assert(Cfg::TM == 128 && Cfg::TN == 128 && Cfg::KC == 16 && Cfg::NT == 256, "written for 128 x 128 x 16 stages, 4 waves");
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, BLK = 128 * KC;        // doubles per operand block
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int t = r % ntri;
+    const int s = (r / ntri) * 8 + xcd;
+    if (s >= S) return;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const bool same = ti == tj;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int lr = lane & 15, lk = lane >> 4;
+    const bool mfma_on = !(same && wave == 1);                        // upper 64 x 64 block of a diagonal tile
+
+    double4_t acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t nkb = Wld / KC;
+    const int nchunks = KS / KC;
+    // lane l of a piece fills LDS row l/8, chunk position l%8 of the piece's 8 rows from global chunk (l%8) ^ (l/8)
+    const int lsrc = (lane >> 3) * KC + (((lane & 7) ^ (lane >> 3)) << 1);
+    const double *Ab = Wt + ((int64_t)ti * nkb + (int64_t)s * nchunks) * BLK + wave * 4 * 128 + lsrc;
+    const double *Bb = Wt + ((int64_t)tj * nkb + (int64_t)s * nchunks) * BLK + wave * 4 * 128 + lsrc;
+    auto issue = [&](int buf, int chunk) {
+        double *As = smem + buf * (2 * BLK) + wave * 4 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(Ab + (int64_t)chunk * BLK + i * 128), (lds_void_t *)(As + i * 128), 16, 0, 0);
+        if (!same) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(Bb + (int64_t)chunk * BLK + i * 128), (lds_void_t *)(As + BLK + i * 128), 16,
+                                                 0, 0);
+        }
+    };
+    int koff[KC / 4];                                 // position of k = 4 ks + lk in this lane's rows (row & 7 == lr & 7)
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+        const int k = 4 * ks + lk;
+        koff[ks] = (((k >> 1) ^ (lr & 7)) << 1) | (k & 1);
+    }
+    auto compute_stage = [&](int buf) {
+        if (!mfma_on) return;
+        const double *As = smem + buf * (2 * BLK) + (wm * (WM * 16) + lr) * KC;
+        const double *Bs = smem + buf * (2 * BLK) + (same ? 0 : BLK) + (wn * (WN * 16) + lr) * KC;
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double a[WM], bb[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) a[m] = As[m * 16 * KC + koff[ks]];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bb[n] = Bs[n * 16 * KC + koff[ks]];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[n], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+        issue((c + 1) & 1, min(c + 1, nchunks - 1));       // past the end: the last block again (nobody reads it)
+        compute_stage(c & 1);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+
+    double *out = Kslab + ((int64_t)s * ntri + t) * (Cfg::TM * Cfg::TN);
+    if (mfma_on) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[tile_row<Cfg>(m, j) * Cfg::TN + tile_col<Cfg>(n)] = acc[m][n][j];
+    }
 }
 
 // ---------------------------------------------------------------------------
