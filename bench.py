@@ -158,27 +158,25 @@ def cpu_baseline(N, Q, o, budget_s=12.0):
 
 
 def run_scf_steps(scf, fb, steps, warmup, barrier):
-    """W untimed + K timed SCF iterations; HIP-event kernel records and the collective events of every timed step."""
+    """W untimed + K timed SCF iterations.  No host call but scf.step() inside the timed loop: the library sums the
+    HIP-event times of every build's launches itself (jcdf_kernel_stats_total), the collectives are timed by device events."""
     for _ in range(warmup):
         scf.step()
-    kstats, fock_s = {}, []
     fb.time_collectives = True
     fb.collective_events = []
     barrier()
+    fb.h.kernel_stats_total(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         scf.step()
-        # HIP-event timings of the launches of this step (events already complete: step() syncs on E)
-        for ks in fb.h.kernel_stats():
-            d = kstats.setdefault(ks["name"], dict(seconds=0.0, n=0, flops=ks["flops"], alg_flops=ks["alg_flops"],
-                                                   alg_bytes=ks["alg_bytes"]))
-            d["seconds"] += ks["seconds"]; d["n"] += 1
-        fock_s.append(fb.h.synchronize().fock_time)
     barrier()
     elapsed = time.perf_counter() - t0
+    recs, nb, fock_sum = fb.h.kernel_stats_total(reset=True)
+    nb = max(nb, 1)
+    kstats = {r["name"]: dict(seconds=r["seconds"], n=nb, flops=r["flops"], alg_flops=r["alg_flops"], alg_bytes=r["alg_bytes"]) for r in recs}
     coll_ms = fb.collective_ms() / steps
     fb.time_collectives = False
-    return elapsed, kstats, float(np.mean(fock_s)) * 1e3, coll_ms
+    return elapsed, kstats, fock_sum / nb * 1e3, coll_ms
 
 
 def max_over_ranks(x, world, dev):

@@ -274,6 +274,12 @@ int64_t jcdf_device_bytes(const jcdf_handle *h);
 /* Per-kernel stats of the last build; returns the number of records written
  * (<= max_records). */
 int32_t jcdf_kernel_stats(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records);
+/* The same records with `seconds` SUMMED over all builds since the last reset (the event times of a build are folded in
+ * when the next build is enqueued, or here for the last one), *n_builds = builds in the sums, *fock_seconds = summed
+ * whole-build time: per-launch averages over a timed loop without any host call inside the loop.  A build that was
+ * still running when its successor was enqueued is left out of the sums (and of *n_builds). */
+int32_t jcdf_kernel_stats_total(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records, int64_t *n_builds, double *fock_seconds,
+                                int32_t reset);
 
 #ifdef __cplusplus
 }

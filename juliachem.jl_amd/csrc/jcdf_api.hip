@@ -35,6 +35,7 @@ struct KernelRec {
     const char *name;
     hipEvent_t e0, e1;
     double flops, alg_flops, alg_bytes;
+    double sum_seconds;      // accumulated over the builds folded so far (jcdf_kernel_stats_total)
 };
 
 }  // namespace
@@ -80,6 +81,9 @@ struct jcdf_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timed_host_copy = false;
     bool pending = false;
+    bool unfolded = false;              // the last build's event times are not yet in the accumulators
+    int64_t builds_folded = 0;
+    double fock_sum_seconds = 0.0;
 };
 
 namespace {
@@ -288,8 +292,28 @@ KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t s
     return r;
 }
 
+double elapsed_s(hipEvent_t a, hipEvent_t b);
+
+// Adds the event times of the last build to the running sums (jcdf_kernel_stats_total) — called before its events are
+// recorded again.  wait = false: only if that build has already finished (never blocks the enqueue path).
+void fold_last_build(jcdf_handle *h, bool wait)
+{
+    if (!h->unfolded || h->recs.empty()) return;
+    if (wait) {
+        if (hipEventSynchronize(h->ev_end) != hipSuccess) return;
+    } else if (hipEventQuery(h->ev_end) != hipSuccess) {
+        h->unfolded = false;                       // still running: this build is left out of the sums
+        return;
+    }
+    for (auto &r : h->recs) r.sum_seconds += elapsed_s(r.e0, r.e1);
+    h->fock_sum_seconds += elapsed_s(h->ev_begin, h->ev_end);
+    h->builds_folded++;
+    h->unfolded = false;
+}
+
 int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t st)
 {
+    fold_last_build(h, false);
     const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o, P = (double)h->P;
     HipAcc ok;
     size_t k = 0;
@@ -373,6 +397,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     ok(hipGetLastError());
     if (ok.first != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("Fock build enqueue: ") + hipGetErrorString(ok.first));
     h->pending = true;
+    h->unfolded = true;
     return JCDF_OK;
 }
 
@@ -1547,6 +1572,33 @@ int32_t jcdf_kernel_stats(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_rec
         out[n].alg_flops = r.alg_flops;
         out[n].alg_bytes = r.alg_bytes;
         ++n;
+    }
+    return n;
+}
+
+int32_t jcdf_kernel_stats_total(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records, int64_t *n_builds, double *fock_seconds,
+                                int32_t reset)
+{
+    if (!h) return 0;
+    fold_last_build(h, true);
+    int32_t n = 0;
+    if (out)
+        for (auto &r : h->recs) {
+            if (n >= max_records) break;
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::snprintf(out[n].name, sizeof(out[n].name), "%s", r.name ? r.name : "?");
+            out[n].seconds = r.sum_seconds;
+            out[n].flops = r.flops;
+            out[n].alg_flops = r.alg_flops;
+            out[n].alg_bytes = r.alg_bytes;
+            ++n;
+        }
+    if (n_builds) *n_builds = h->builds_folded;
+    if (fock_seconds) *fock_seconds = h->fock_sum_seconds;
+    if (reset) {
+        for (auto &r : h->recs) r.sum_seconds = 0.0;
+        h->builds_folded = 0;
+        h->fock_sum_seconds = 0.0;
     }
     return n;
 }

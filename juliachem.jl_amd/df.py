@@ -454,6 +454,19 @@ class JCDFHandle:
                      alg_flops=arr[i].alg_flops, alg_bytes=arr[i].alg_bytes) for i in range(n)]
 
 
+def _kernel_stats_total(self, reset: bool = False):
+    """(records with `seconds` summed over the builds since the last reset, number of builds, summed whole-build seconds)"""
+    arr = (jcdf_kernel_stat * 16)()
+    nb, fs = C.c_int64(0), C.c_double(0.0)
+    n = self._lib.jcdf_kernel_stats_total(self._h, arr, 16, C.byref(nb), C.byref(fs), 1 if reset else 0)
+    recs = [dict(name=arr[i].name.decode(), seconds=arr[i].seconds, flops=arr[i].flops, alg_flops=arr[i].alg_flops,
+                 alg_bytes=arr[i].alg_bytes) for i in range(n)]
+    return recs, int(nb.value), float(fs.value)
+
+
+JCDFHandle.kernel_stats_total = _kernel_stats_total
+
+
 def lapack_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
     """L^-1 exactly as the reference forms it on the host: LAPACK.potrf!('L') + trtri!('L','N')
     (GPUDF.jl:890-891, DensityFitting.jl:137-140), through scipy's LAPACK.  Upper triangle zeroed
