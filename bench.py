@@ -188,7 +188,7 @@ def max_over_ranks(x, world, dev):
     return float(tt.item())
 
 
-def measure_w50(args, world, rank, local, dev, barrier, kept):
+def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=None):
     """BASELINE config 4: the (H2O)50 / cc-pVDZ shape (1250 / 4800 / 250), aux index sharded over the ranks, one F
     all-reduce per iteration.  kept = None: unscreened map (60 GB of B in all); kept = 0.13: a scattered 3-D-cluster map
     with the kept fraction of the real cluster (profiles/r02_w50_real_run.txt) — what the reference's adaptive rule runs
@@ -225,11 +225,11 @@ def measure_w50(args, world, rank, local, dev, barrier, kept):
         fb.h.set_B_columns_device(c0, c1, blk.data_ptr())
     del g1, g2, blk
     torch.cuda.empty_cache()
-    scf = DeviceSCF(fb, H, np.eye(N), 0.0, density_solver=args.density_solver)
+    scf = DeviceSCF(fb, H, np.eye(N), 0.0, density_solver=density_solver or args.density_solver)
     torch.cuda.synchronize(dev)
     t_setup = time.perf_counter() - t_setup
     steps = max(3, min(args.steps, 10))
-    elapsed, kstats, fock_ms, coll_ms = run_scf_steps(scf, fb, steps, 2, barrier)
+    elapsed, kstats, fock_ms, coll_ms = run_scf_steps(scf, fb, steps, 8 if density_solver == "sp2" else 2, barrier)
     elapsed = max_over_ranks(elapsed, world, dev)
     nbytes = fb.h.device_bytes()
     rep = scf.solver_report()
@@ -242,7 +242,8 @@ def measure_w50(args, world, rank, local, dev, barrier, kept):
            "kept_pair_fraction": P / float(N * N), "aux_rows_rank0": Ql, "device_GB_rank0": nbytes / 1e9,
            "fock_build_useful_tflops": fock_useful_flops(N, Q, o, P) / (fock_ms * 1e-3) / 1e12,
            "fock_build_tflops_dense_formula": fock_alg_flops(N, Q, o) / (fock_ms * 1e-3) / 1e12,
-           "setup_s": t_setup, "eigensolver": rep}
+           "setup_s": t_setup, "eigensolver": rep, "density_solver": scf.density_solver,
+           "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks}
     return out
 
 
@@ -349,7 +350,10 @@ def main():
         w50 = {"workload": "(H2O)50 / cc-pVDZ + cc-pVDZ-RIFIT shaped DF-RHF SCF iteration: N=1250 AO, Q=4800 aux, n_occ=250, aux index "
                            "sharded over %d GPU(s), C broadcast + F all-reduce over RCCL per iteration" % world,
                "screened_13pct": measure_w50(args, world, rank, local, dev, barrier, 0.13),
-               "dense_map": measure_w50(args, world, rank, local, dev, barrier, None)}
+               "dense_map": measure_w50(args, world, rank, local, dev, barrier, None),
+               # the same screened problem with the optional spectral-projection density solver (no eigensolve per
+               # iteration): what the replicated part costs strong scaling — informational, like `alt`
+               "screened_13pct_sp2": measure_w50(args, world, rank, local, dev, barrier, 0.13, density_solver="sp2")}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -39,6 +39,7 @@ def test_bench_prints_the_contract_line():
     assert d["allreduce_ms"] == 0.0 and abs(d["replicated_ms"] + d["fock_build_ms"] - d["ms_per_step"]) < 1e-9
     # the strong-scaling workload of north_star ((H2O)50 shape) measured in the same run, never `value`
     w50 = d["scaling_w50"]
+    assert w50["screened_13pct_sp2"]["density_solver"] == "sp2" and w50["screened_13pct_sp2"]["replicated_ms"] < w50["screened_13pct"]["replicated_ms"]
     for kind in ("screened_13pct", "dense_map"):
         for k in ("value", "ms_per_step", "fock_build_ms", "allreduce_ms", "replicated_ms", "kernels_ms", "device_GB_rank0"):
             assert k in w50[kind], (kind, k)

@@ -11,7 +11,7 @@ if d.get("alt"):
     print("alt", d["alt"]["value"], d["alt"].get("replicated_ms"))
 for k, v in (d.get("scaling_w50") or {}).items():
     if isinstance(v, dict):
-        print(k, {kk: v[kk] for kk in ["value", "ms_per_step", "fock_build_ms", "replicated_ms", "allreduce_ms", "device_GB_rank0", "kernels_ms"]})
+        print(k, {kk: v.get(kk) for kk in ["value", "ms_per_step", "fock_build_ms", "replicated_ms", "allreduce_ms", "device_GB_rank0", "kernels_ms", "sp2_steps", "sp2_fallbacks"]})
 print("real", d.get("real_molecule"))
 cb = d.get("cpu_baseline")
 if cb:
