@@ -268,6 +268,11 @@ int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t le
                               double *d_work /* 64 * nd doubles */);
 int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F);
 
+/* Diagnostic only (environment JCDF_W_ABLATE=32 with JCDF_W_REM=0 at jcdf_configure, 81..96 occupied orbitals): shader
+ * cycles per wave spent in the five segments of the W kernel's phases during the last build — DMA issue, operand reads +
+ * MFMA issue, index loads / epilogue, counted vmcnt wait, barrier — and the number of phases; 6 words per wave. */
+int64_t jcdf_w_stall_cycles(jcdf_handle *h, unsigned long long *out, int64_t max_waves);
+
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */
 int64_t jcdf_device_bytes(const jcdf_handle *h);

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "jcdf_diis_push_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P]),
     "jcdf_diis_dots_device": (C.c_int32, [_P, C.c_int32, C.c_int32, _I64, _P, _P, _P]),
     "jcdf_diis_mix_device": (C.c_int32, [_P, C.c_int32, _I64, _I64, _P, _P, _P]),
+    "jcdf_w_stall_cycles": (_I64, [_P, _P, _I64]),
     "jcdf_device_bytes": (_I64, [_P]),
     "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),
     "jcdf_kernel_stats_total": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),

@@ -69,6 +69,7 @@ struct jcdf_handle {
     int64_t ldl = 0, linv_rows = 0;
     int *dWchunk = nullptr, *dStgC = nullptr, *dStgQ = nullptr, *dStgP = nullptr;   // stage table of the W kernel
     int *dJrow = nullptr, *dCmap = nullptr;              // packed rows with q >= p; (q,p) -> index into J
+    unsigned long long *dStall = nullptr;                // JCDF_W_ABLATE=32: per-wave segment cycles of the W kernel (diagnostic)
     double *dStage = nullptr;                            // setup staging for pushed three-centre blocks, freed after setup
     int64_t stage_doubles = 0;
     int64_t bytes = 0;
@@ -150,6 +151,7 @@ void free_all(jcdf_handle *h)
     int **ibufs[] = {&h->dWchunk, &h->dStgC, &h->dStgQ, &h->dStgP, &h->dJrow, &h->dCmap};
     for (auto b : ibufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (h->dStall) { (void)hipFree(h->dStall); h->dStall = nullptr; }
     for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     h->recs.clear();
     h->bytes = 0;
@@ -168,7 +170,7 @@ hipError_t launch_W_dma_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
     hipLaunchKernelGGL((k_exchange_W_dma<WM, WVM, WN>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
                        h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
-                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0, h->dStall);
     return hipSuccess;
 }
 
@@ -183,7 +185,7 @@ hipError_t launch_W_ablate_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
     hipLaunchKernelGGL((k_exchange_W_dma<6, 1, 2, ABL>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
                        h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
-                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0, h->dStall);
     return hipSuccess;
 }
 
@@ -198,7 +200,7 @@ hipError_t launch_W_rem_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     const int64_t nblk = (int64_t)h->n_chunks * h->n_mtiles * h->n_qt;
     hipLaunchKernelGGL((k_exchange_W_dma<WM, 1, 2, 0, REM>), dim3((unsigned)nblk), dim3(D::NT), D::SMEM_BYTES, st, h->dB, h->ldq,
                        h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
-                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0);
+                       h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0, h->dStall);
     return hipSuccess;
 }
 
@@ -248,6 +250,7 @@ hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
             case 16: return launch_W_ablate_t<16>(h, st, attr);
             case 20: return launch_W_ablate_t<20>(h, st, attr);
             case 30: return launch_W_ablate_t<30>(h, st, attr);
+            case 32: return launch_W_ablate_t<32>(h, st, attr);
             default: break;
         }
     }
@@ -899,8 +902,13 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         stg_c.reserve((size_t)total_stages * kcw);
         stg_q.reserve((size_t)total_stages * kcw);
         stg_p.reserve((size_t)total_stages);
-        // ~6 workgroups per resident slot (2 per CU), at least one p and >= 256 contraction rows each: a workgroup's
-        // pipeline fill is paid once per chunk (C20H42 shape: 64 stages per chunk 1.76 ms, 128: 1.66, 512: 1.64)
+        // Chunks of consecutive p closed greedily at a target stage count: ~6 workgroups per resident slot (2 per CU), at
+        // least 256 contraction rows each — a workgroup's pipeline fill is paid once per chunk (C20H42 shape: 64 stages
+        // per chunk 1.76 ms, 128: 1.66, 512: 1.64), and many chunks let the dispatcher even out unequal K_p.  Measured
+        // against it on one box (gpurun_out/r02_pf15.txt) and not better: exactly one chunk per resident slot (C20H42
+        // 1.60-1.68 vs 1.57-1.61 ms; (H2O)50 13 % kept 9.5 vs 9.5) and equalised chunk sizes (1.67-1.70: with 64 stages per
+        // p the greedy rule happens to give 170 equal chunks of 3 p, the equalised one 2 and 3 p mixed).  The slots stay
+        // busy either way: sum of workgroup times / slots = kernel time (profiles/r02_w_stall.txt).
         const int64_t tiles = total_stages * h->n_qt * h->n_mtiles;
         int64_t target = std::min<int64_t>(4096 / kcw, std::max<int64_t>(256 / kcw, tiles / (6 * 2 * (int64_t)h->num_cu)));
         if (const char *e = getenv("JCDF_W_CHUNK_STAGES")) target = std::max(1, atoi(e));
@@ -990,6 +998,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     if ((rc = dev_upload(h, &h->dStgP, stg_p))) return rc;
     if ((rc = dev_upload(h, &h->dJrow, jrow))) return rc;
     if ((rc = dev_upload(h, &h->dCmap, cmap))) return rc;
+    if (h->w_ablate == 32 && (rc = dev_alloc(h, &h->dStall, (int64_t)h->n_chunks * h->n_mtiles * h->n_qt * 8 * 6, true))) return rc;
     JCDF_HIP(h, hipStreamSynchronize(h->stream));       // the host vectors above go out of scope
     h->configured = true;
     return JCDF_OK;
@@ -1551,6 +1560,18 @@ int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, co
     hipLaunchKernelGGL(k_diis_mix, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_f_hist, n * n, (int)nd, d_coef,
                        (int)n, d_F, ld);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+// Diagnostic (JCDF_W_ABLATE=32, C20H42-shaped form only): per-wave cycles of the five segments of the W kernel's phases
+// from the last build: out[(block * waves + wave) * 6 + {issue, mfma, misc, vmcnt wait, barrier, phases}].  Returns the
+// number of wave records written, 0 if the diagnostic build is not active.
+int64_t jcdf_w_stall_cycles(jcdf_handle *h, unsigned long long *out, int64_t max_waves)
+{
+    if (!h || !h->dStall || !out) return 0;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+    const int64_t waves = std::min<int64_t>(max_waves, (int64_t)h->n_chunks * h->n_mtiles * h->n_qt * 4);
+    if (hipMemcpy(out, h->dStall, (size_t)waves * 6 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return waves;
 }
 
 int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }

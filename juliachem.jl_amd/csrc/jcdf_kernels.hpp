@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN, REM>::WAVES_PER_SI
     const double *__restrict__ Bp, int64_t ldq, const double *__restrict__ Cpad, const double *__restrict__ Cv,
     double *__restrict__ Wt, int64_t Wld, double *__restrict__ vpart, int vld, int o, int opad, int n_mt, int n_qt,
     const int *__restrict__ wchunk, const int *__restrict__ stg_c, const int *__restrict__ stg_q,
-    const int *__restrict__ stg_p, int skip_partial)
+    const int *__restrict__ stg_p, int skip_partial, unsigned long long *__restrict__ stall)
 {
     using D = WDmaCfg<WM, WVM, WN, REM>;
     constexpr int TM = D::TM, TMA = D::TMA, TN = D::TN, LDAS = D::LDAS, LDBS = D::LDBS, NW = D::NW, AH = D::AH, BH = D::BH;
@@ -482,23 +482,48 @@ __global__ __launch_bounds__(256 * WVM, (WDmaCfg<WM, WVM, WN, REM>::WAVES_PER_SI
     wait_vmcnt<FLY>();
     __builtin_amdgcn_s_barrier();
     int cur = 0, nxt = AHEAD;                        // ring slots of stage t and of stage t + AHEAD
+    // ABL & 32: diagnostic build with s_memtime stamps around the five segments of a phase (shader cycles per wave, summed
+    // over the chunk's phases; tools/w_stall.py, profiles/r02_w_stall.txt).  The stamps cost cycles themselves.
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (ABL & 32) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            seg[k] += now - tprev;
+            tprev = now;
+        }
+    };
+    if constexpr (ABL & 32) tprev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nst; ++t) {
         if constexpr (!(ABL & 2)) issue(nxt);        // -> the buffer phase t-1 has finished reading
+        stamp(0);                                    // DMA issue (address arithmetic + 2 G global_load_lds)
         compute_stage(cur);
         compute_rem(cur);
+        stamp(1);                                    // LDS operand reads + MFMA issue (+ the VALU remainder)
         const int p = stg_p[t0 + t];
         next_idx(t + AHEAD + 1);
         if (p >= 0) epilogue_rem(p);
         if (p >= 0 && active) {
             epilogue(p);
+            stamp(2);                                // scalar index loads, epilogue at the end of a p
             // behind stage t+1's pieces the counter now holds FLY pieces and this wave's W stores
             if constexpr (!(ABL & 4)) wait_vmcnt<(FLY + D::STORES > 63) ? 63 : FLY + D::STORES>();
         } else {
+            stamp(2);
             if constexpr (!(ABL & 4)) wait_vmcnt<FLY>();
         }
+        stamp(3);                                    // counted vmcnt wait (stage t+1's DMA)
         if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        stamp(4);                                    // barrier
         cur = (cur + 1 == RING) ? 0 : cur + 1;
         nxt = (nxt + 1 == RING) ? 0 : nxt + 1;
+    }
+    if constexpr (ABL & 32) {
+        if (stall && lane == 0) {
+            unsigned long long *o_ = stall + ((size_t)blockIdx.x * NW + wave) * 6;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o_[k] = seg[k];
+            o_[5] = (unsigned long long)nst;
+        }
     }
     wait_vmcnt<0>();                                 // the re-issued tail stages still write this workgroup's LDS
 
