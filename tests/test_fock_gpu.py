@@ -981,3 +981,57 @@ def test_exchange_split_k_is_result_invariant(m, monkeypatch):
     F, _ = h.fock_build(s.C[:, :o])
     assert _rel(F, ref) < RTOL and np.array_equal(F, F.T)
     h.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 32, 32), (64, 96, 160), (512, 512, 512), (96, 512, 1280)])
+def test_own_gemm_kernels_match_torch(M, N, K):
+    """jcdf_gemm_tn_device / jcdf_gemm_nt_device (the dense products of the device SCF step, csrc/jcdf_blas.hpp) against
+    torch fp64 matmul; tolerance 1e-13 relative to max|C| (different summation order only)."""
+    import ctypes
+    import torch
+    lib = jc._lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    A = torch.randn((K, M), dtype=torch.float64, device=dev, generator=g)
+    B = torch.randn((K, N), dtype=torch.float64, device=dev, generator=g)
+    C = torch.zeros((M, N), dtype=torch.float64, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.jcdf_gemm_tn_device(st, M, N, K, 0.5, p(A), M, p(B), N, p(C), N) == 0
+    ref = 0.5 * (A.T @ B)
+    assert float((C - ref).abs().max() / ref.abs().max()) < 1e-13
+    An = torch.randn((M, K), dtype=torch.float64, device=dev, generator=g)
+    Bn = torch.randn((N, K), dtype=torch.float64, device=dev, generator=g)
+    assert lib.jcdf_gemm_nt_device(st, M, N, K, p(An), K, p(Bn), K, p(C), N) == 0
+    ref = An @ Bn.T
+    assert float((C - ref).abs().max() / ref.abs().max()) < 1e-13
+    assert lib.jcdf_gemm_tn_device(st, M + 1, N, K, 1.0, p(A), M, p(B), N, p(C), N) == 1          # JCDF_ERR_INVALID: not a multiple of 32
+
+
+def test_diis_history_kernels_match_torch():
+    """jcdf_diis_push / dots / mix_device against torch on a padded 70 x 70 problem (ld 96)."""
+    import ctypes
+    import torch
+    lib = jc._lib.load()
+    dev = torch.device("cuda", 0)
+    n, ld, nd, head = 70, 96, 6, 4
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    T = torch.randn((ld, ld), dtype=torch.float64, device=dev, generator=g)
+    F = torch.randn((ld, ld), dtype=torch.float64, device=dev, generator=g)
+    e_hist = torch.randn((nd, n * n), dtype=torch.float64, device=dev, generator=g)
+    f_hist = torch.randn((nd, n * n), dtype=torch.float64, device=dev, generator=g)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.jcdf_diis_push_device(st, n, ld, p(T), p(F), p(e_hist[head]), p(f_hist[head])) == 0
+    assert torch.equal(e_hist[head].reshape(n, n), T[:n, :n].T - T[:n, :n])
+    assert torch.equal(f_hist[head].reshape(n, n), F[:n, :n])
+    dots = torch.zeros(nd, dtype=torch.float64, device=dev)
+    work = torch.zeros(64 * nd, dtype=torch.float64, device=dev)
+    assert lib.jcdf_diis_dots_device(st, nd, head, n * n, p(e_hist), p(dots), p(work)) == 0
+    ref = e_hist @ e_hist[head]
+    assert float((dots - ref).abs().max() / ref.abs().max()) < 1e-13
+    coef = torch.tensor([0.3, 0.0, -0.2, 0.0, 0.9, 0.0], dtype=torch.float64, device=dev)
+    out = torch.full((ld, ld), 7.0, dtype=torch.float64, device=dev)
+    assert lib.jcdf_diis_mix_device(st, nd, n, ld, p(f_hist), p(coef), p(out)) == 0
+    ref = (coef[:, None] * f_hist).sum(0).reshape(n, n)
+    assert float((out[:n, :n] - ref).abs().max()) < 1e-13 and float(out[n:, :].min()) == 7.0      # padding untouched
