@@ -332,9 +332,6 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     {
         KernelRec &r = rec_begin(h, k++, "k_exchange_W", st, ok);
         ok(launch_W(h, st));
-        const int nparts = h->n_chunks * h->n_mtiles;
-        hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 31) / 32)), dim3(256), 0, st, h->dVpart, nparts, h->vld,
-                           (int)h->Ql, (int)h->ldq, h->dV);
         // incl. all padding: orbitals to opad, K_p to whole stages, the aux index to whole 32-column wave tiles (DMA kernel)
         r.flops = 2.0 * (double)h->kcw * (double)h->n_stages *
                   ((double)(h->opad - (h->w_rem ? 16 : 0)) *
@@ -344,7 +341,14 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         r.alg_bytes = 8.0 * Ql * P + 8.0 * Ql * o * N;               // B read once + W written once
         ok(hipEventRecord(r.e1, st));
     }
+    // V from the W kernel's partials: only the Coulomb pass needs it, so it goes in front of J (on J's stream)
+    auto run_reduce_V = [&](hipStream_t sv) {
+        const int nparts = h->n_chunks * h->n_mtiles;
+        hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 31) / 32)), dim3(256), 0, sv, h->dVpart, nparts, h->vld,
+                           (int)h->Ql, (int)h->ldq, h->dV);
+    };
     auto run_J = [&](size_t slot, hipStream_t st) {
+        run_reduce_V(st);
         KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st, ok);
         const int64_t groups = (h->Plow + 4 * J_ROWS - 1) / (4 * J_ROWS);
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)h->num_cu * JCDF_J_BLOCKS_PER_CU));
