@@ -204,6 +204,20 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* The same reduction in two stages (csrc/jcdf_sbr.hpp): dense -> band of half-width 16 (one Householder QR per panel of
+ * 16 columns inside one workgroup + MFMA block-reflector updates) -> tridiagonal (bulge chasing in the LDS of one
+ * workgroup) — 3 n/16 kernel boundaries instead of n chip-wide hand-offs.  jcdf_sytrd2_device leaves D, E (device, n and
+ * n-1), the stage-1 orthogonal factor in d_Q (n x n row-major, leading dimension ldq) and the stage-2 reflectors in
+ * d_work; jcdf_sytrd2_apply_q_device (any stream ordered behind the first call; it needs neither D nor E, so it may run
+ * beside jcdf_stedc_device) completes d_Q to the Q of A = Q T Q^T.  d_A (symmetric, fully stored) is overwritten.
+ * The int at byte offset 8 of d_work is non-zero afterwards if a wait inside the chase gave up (result invalid).
+ * n <= jcdf_sytrd2_max_n() (the band must fit the LDS of one CU: 598). */
+int64_t jcdf_sytrd2_max_n(void);
+int64_t jcdf_sytrd2_workspace_bytes(int64_t n);
+int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_Q,
+                           int64_t ldq, void *d_work, int64_t work_bytes);
+int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t ldq, const void *d_work,
+                                   int64_t work_bytes);
 /* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
  * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
  * d_Bmat nd x nd ring buffer of error-vector dot products (row and column `head` are first overwritten with

@@ -12,6 +12,7 @@
 #include "jcdf_sp2.hpp"
 #include "jcdf_scf.hpp"
 #include "jcdf_blas.hpp"
+#include "jcdf_sbr.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -1336,6 +1337,100 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
     int64_t n = 64;
     while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;
     return n;
+}
+
+// ---- two-stage tridiagonalisation (jcdf_sbr.hpp): dense -> band (16) -> tridiagonal, Q accumulated forwards -------------
+namespace {
+struct Sytrd2Layout {
+    int64_t n, tmax, ntile;
+    size_t off_v, off_y, off_w, off_t, off_m1, off_ab, off_log, total;
+};
+Sytrd2Layout sytrd2_layout(int64_t n)
+{
+    Sytrd2Layout L;
+    L.n = n;
+    L.tmax = n >= 3 ? (n - 3) / SB + 1 : 1;
+    L.ntile = (n + 15) / 16;
+    size_t o = 64;
+    auto take = [&](size_t doubles) { const size_t at = o; o += (doubles * 8 + 63) / 64 * 64; return at; };
+    L.off_v = take((size_t)n * 16);
+    L.off_y = take((size_t)n * 16);
+    L.off_w = take((size_t)n * 16);
+    L.off_t = take(256);
+    L.off_m1 = take((size_t)L.ntile * 256);
+    L.off_ab = take((size_t)n * SBW);
+    L.off_log = take((size_t)n * L.tmax * 16);
+    L.total = o;
+    return L;
+}
+constexpr int SB2ST_WAVES = 16;
+size_t sb2st_lds(int64_t n) { return (size_t)(n + 16) * SBW * 8 + SB2ST_WAVES * 48 * 8 + (size_t)(n + 2) * 4; }
+}  // namespace
+
+int64_t jcdf_sytrd2_max_n(void)
+{
+    int64_t n = 64;
+    while (sb2st_lds(n + 1) <= 160 * 1024) ++n;
+    return std::min<int64_t>(n, 256 * 5 + 16);                  // the panel kernel holds at most 5 rows per thread
+}
+
+int64_t jcdf_sytrd2_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    return (int64_t)sytrd2_layout(n).total;
+}
+
+int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_Q, int64_t ldq,
+                           void *d_work, int64_t work_bytes)
+{
+    if (n <= 0 || n > jcdf_sytrd2_max_n() || !d_A || lda < n || !d_D || !d_E || !d_Q || ldq < n || !d_work ||
+        work_bytes < jcdf_sytrd2_workspace_bytes(n))
+        return JCDF_ERR_INVALID;
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const Sytrd2Layout L = sytrd2_layout(n);
+    char *w = (char *)d_work;
+    int *err = (int *)(w + 8);
+    double *V = (double *)(w + L.off_v), *Y = (double *)(w + L.off_y), *W = (double *)(w + L.off_w), *T = (double *)(w + L.off_t);
+    double *M1p = (double *)(w + L.off_m1), *AB = (double *)(w + L.off_ab), *vlog = (double *)(w + L.off_log);
+    if (hipMemsetAsync(w, 0, 64, st) != hipSuccess) return JCDF_ERR_HIP;
+    const int ni = (int)n;
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_Q, (int)ldq, ni);
+    for (int k = 0; ni - (k + 1) * SB >= 2; ++k) {
+        const int r0 = (k + 1) * SB, m = ni - r0, nrow = (m + 255) / 256;
+        if (nrow <= 1) hipLaunchKernelGGL(k_sbr_panel<1>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
+        else if (nrow <= 2) hipLaunchKernelGGL(k_sbr_panel<2>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
+        else if (nrow <= 3) hipLaunchKernelGGL(k_sbr_panel<3>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
+        else hipLaunchKernelGGL(k_sbr_panel<5>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
+        const int ntile = (m + 15) / 16, nt1 = (m + 31) / 32;
+        hipLaunchKernelGGL(k_sbr_y, dim3((unsigned)ntile), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, Y, M1p);
+        hipLaunchKernelGGL(k_sbr_w, dim3((unsigned)ntile), dim3(256), 0, st, m, V, Y, T, M1p, ntile, W);
+        hipLaunchKernelGGL(k_sbr_update, dim3((unsigned)(nt1 * nt1 + (ni + 15) / 16)), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, W,
+                           T, d_Q, (int)ldq, nt1);
+    }
+    hipLaunchKernelGGL(k_sbr_extract, dim3((unsigned)((n * SBW + 255) / 256)), dim3(256), 0, st, d_A, (int)lda, ni, AB);
+    const size_t lds = sb2st_lds(n);
+    if (hipFuncSetAttribute((const void *)k_sb2st_chase<SB2ST_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return JCDF_ERR_HIP;
+    hipLaunchKernelGGL(k_sb2st_chase<SB2ST_WAVES>, dim3(1), dim3(SB2ST_WAVES * 64), lds, st, AB, ni, d_D, d_E, vlog, (int)L.tmax, err);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t ldq, const void *d_work, int64_t work_bytes)
+{
+    if (n <= 0 || n > jcdf_sytrd2_max_n() || !d_Q || ldq < n || !d_work || work_bytes < jcdf_sytrd2_workspace_bytes(n))
+        return JCDF_ERR_INVALID;
+    if (n < 3) return JCDF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const Sytrd2Layout L = sytrd2_layout(n);
+    const double *vlog = (const double *)((const char *)d_work + L.off_log);
+    constexpr int RPL = 1;
+    const size_t lds = (size_t)16 * RPL * (n + 17) * 8;
+    if (hipFuncSetAttribute((const void *)k_sb2st_apply_q<RPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return JCDF_ERR_HIP;
+    hipLaunchKernelGGL(k_sb2st_apply_q<RPL>, dim3((unsigned)((n + 16 * RPL - 1) / (16 * RPL))), dim3(256), lds, st, d_Q, (int)ldq, (int)n,
+                       vlog, (int)L.tmax);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int32_t solve, double *d_Bmat, const double *d_dots,
