@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libjcdf_hip.so")
+LIB_PATH = os.environ.get("JCDF_LIB_PATH") or os.path.join(_HERE, "lib", "libjcdf_hip.so")   # (override: diagnostic builds of tools/)
 
 
 class JCDFError(RuntimeError):

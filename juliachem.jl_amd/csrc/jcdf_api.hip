@@ -1391,7 +1391,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     const Sytrd2Layout L = sytrd2_layout(n);
     char *w = (char *)d_work;
     int *err = (int *)(w + 8);
-    double *V = (double *)(w + L.off_v), *Y = (double *)(w + L.off_y), *W = (double *)(w + L.off_w), *T = (double *)(w + L.off_t);
+    double *V = (double *)(w + L.off_v), *Y = (double *)(w + L.off_y), *T = (double *)(w + L.off_t);
     double *M1p = (double *)(w + L.off_m1), *AB = (double *)(w + L.off_ab), *vlog = (double *)(w + L.off_log);
     if (hipMemsetAsync(w, 0, 64, st) != hipSuccess) return JCDF_ERR_HIP;
     const int ni = (int)n;
@@ -1403,10 +1403,9 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
         else if (nrow <= 3) hipLaunchKernelGGL(k_sbr_panel<3>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
         else hipLaunchKernelGGL(k_sbr_panel<5>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
         const int ntile = (m + 15) / 16, nt1 = (m + 31) / 32;
-        hipLaunchKernelGGL(k_sbr_y, dim3((unsigned)ntile), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, Y, M1p);
-        hipLaunchKernelGGL(k_sbr_w, dim3((unsigned)ntile), dim3(256), 0, st, m, V, Y, T, M1p, ntile, W);
-        hipLaunchKernelGGL(k_sbr_update, dim3((unsigned)(nt1 * nt1 + (ni + 15) / 16)), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, W,
-                           T, d_Q, (int)ldq, nt1);
+        hipLaunchKernelGGL(k_sbr_y, dim3((unsigned)ntile), dim3(SBR_YW * 64), 0, st, d_A, (int)lda, ni, r0, V, Y, M1p);
+        hipLaunchKernelGGL(k_sbr_update, dim3((unsigned)(nt1 * nt1 + (ni + 15) / 16)), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, Y,
+                           T, M1p, ntile, d_Q, (int)ldq, nt1);
     }
     hipLaunchKernelGGL(k_sbr_extract, dim3((unsigned)((n * SBW + 255) / 256)), dim3(256), 0, st, d_A, (int)lda, ni, AB);
     const size_t lds = sb2st_lds(n);
@@ -1416,6 +1415,18 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
+#ifdef JCDF_SB2ST_PROFILE
+extern "C" int32_t jcdf_sb2st_profile(unsigned long long *out, int32_t reset)       // diagnostic builds only (not in jcdf.h)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sb2st_prof), sizeof(unsigned long long) * 16 * 8) != hipSuccess) return JCDF_ERR_HIP;
+    if (reset) {
+        static unsigned long long zero[16 * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sb2st_prof), zero, sizeof(zero)) != hipSuccess) return JCDF_ERR_HIP;
+    }
+    return JCDF_OK;
+}
+#endif
+
 int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t ldq, const void *d_work, int64_t work_bytes)
 {
     if (n <= 0 || n > jcdf_sytrd2_max_n() || !d_Q || ldq < n || !d_work || work_bytes < jcdf_sytrd2_workspace_bytes(n))
@@ -1424,11 +1435,12 @@ int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t
     hipStream_t st = (hipStream_t)stream;
     const Sytrd2Layout L = sytrd2_layout(n);
     const double *vlog = (const double *)((const char *)d_work + L.off_log);
-    constexpr int RPL = 1;
-    const size_t lds = (size_t)16 * RPL * (n + 17) * 8;
-    if (hipFuncSetAttribute((const void *)k_sb2st_apply_q<RPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    constexpr int NWQ = 4, MAXG = 10;                               // one row of Q per wave; 4 MAXG >= tmax (n <= 590 + ...)
+    if (L.tmax > 4 * MAXG) return JCDF_ERR_INVALID;
+    const size_t lds = (size_t)NWQ * (n + 144) * 8;
+    if (hipFuncSetAttribute((const void *)k_sb2st_apply_q<NWQ, MAXG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return JCDF_ERR_HIP;
-    hipLaunchKernelGGL(k_sb2st_apply_q<RPL>, dim3((unsigned)((n + 16 * RPL - 1) / (16 * RPL))), dim3(256), lds, st, d_Q, (int)ldq, (int)n,
+    hipLaunchKernelGGL((k_sb2st_apply_q<NWQ, MAXG>), dim3((unsigned)((n + NWQ - 1) / NWQ)), dim3(NWQ * 64), lds, st, d_Q, (int)ldq, (int)n,
                        vlog, (int)L.tmax);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }

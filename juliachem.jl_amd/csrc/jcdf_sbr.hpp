@@ -18,12 +18,86 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "jcdf_eig.hpp"      // dpp reductions, double4_t comes from jcdf_gemm.hpp via the including file
 
 namespace jcdf {
 
 constexpr int SB = 16;             // half bandwidth after stage 1 = panel width = reflector length of stage 2
 constexpr int SBW = 2 * SB;        // doubles per column of the band storage AB[j][d] = A[j+d][j], d < 2 SB (bulges included)
+
+__device__ __forceinline__ double mk_f64(unsigned lo, unsigned hi) { return __longlong_as_double(((long long)hi << 32) | lo); }
+
+// x + x(lane ^ 16): v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second
+__device__ __forceinline__ double xor16_sum(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);       // (even row's value) + (odd row's value) in both rows
+}
+
+// x + x(lane ^ 32)
+__device__ __forceinline__ double xor32_sum(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);       // (lower half's value) + (upper half's value) in both halves
+}
+
+// sum over the four 16-lane rows of the wave, the same bits in every row
+__device__ __forceinline__ double rows_sum(double x) { return xor32_sum(xor16_sum(x)); }
+
+__device__ __forceinline__ double lane0_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    return mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL)), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)));
+}
+
+
+// a <- a + b where afterwards the lower half-wave holds (a summed over both halves) and the upper half-wave (b summed
+// over both halves): TWO cross-half reductions for one addition (v_permlane32_swap exchanges a's upper with b's lower half)
+__device__ __forceinline__ double pair_sum32(double a, double b)
+{
+    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);
+}
+// the same across the two 16-lane rows of each half: even rows end with a's sum, odd rows with b's
+__device__ __forceinline__ double pair_sum16(double a, double b)
+{
+    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);
+}
+
+// dlarfg scalars without IEEE division / square root (their expansions are ~25 dependent instructions each and this
+// chain is on the critical path of every step): y = rsqrt(alpha^2 + sigma) and r = 1 / (|alpha| + norm) by the
+// hardware estimates + two Newton steps (full double precision), then
+//   beta = -sign(alpha) norm,  tau = (beta - alpha) / beta = 1 + |alpha| y,  scale = 1 / (alpha - beta) = sign(alpha) r.
+__device__ __forceinline__ void house_scalars(double alpha, double sigma, double &tau, double &beta, double &scale)
+{
+    tau = 0.0;
+    beta = alpha;
+    scale = 0.0;
+    if (sigma != 0.0) {
+        const double x = alpha * alpha + sigma;
+        double y = __builtin_amdgcn_rsq(x);
+        y = y * (1.5 - 0.5 * x * y * y);
+        y = y * (1.5 - 0.5 * x * y * y);
+        const double norm = x * y, aa = fabs(alpha);
+        const double dn = aa + norm;
+        double r = __builtin_amdgcn_rcp(dn);
+        r = r * (2.0 - dn * r);
+        r = r * (2.0 - dn * r);
+        beta = -copysign(norm, alpha);
+        tau = 1.0 + aa * y;
+        scale = copysign(r, alpha);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // stage 1
@@ -40,9 +114,10 @@ template <int NROW>
 __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int lda, int n, int k, double *__restrict__ Vbuf,
                                                    double *__restrict__ Tbuf)
 {
-    __shared__ double part[16][256];
+    __shared__ double part[16][64];                     // [value][wave * 16 + lane & 15]: partial sums over 4 lanes each
     __shared__ double tot[16];
     __shared__ double prow[2][16];
+    __shared__ double sS[16][17];                         // S[c'][c] = V[:, c']^T v_c (c' < c) and tau_c on the diagonal, for T
     const int tid = threadIdx.x;
     const int j0 = k * SB, r0 = j0 + SB, m = n - r0;
     double p[NROW][16];
@@ -52,10 +127,10 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
 #pragma unroll
         for (int c = 0; c < 16; ++c) p[q][c] = (i < m) ? A[(size_t)(j0 + c) * lda + r0 + i] : 0.0;
     }
-    double trow[16];                                      // row (tid & 15) of T, redundantly in every 16-lane group
-#pragma unroll
-    for (int c = 0; c < 16; ++c) trow[c] = 0.0;
     const int tr = tid & 15;
+    const int gq = (tid >> 4) & 3;                        // 16-lane row of the wave
+    const int myval = 2 * (gq & 1) + (gq >> 1);           // after the two pair sums this row holds values 4 q + myval
+    double *pdst = &part[myval][(tid >> 6) * 16 + tr];
 
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -70,8 +145,12 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) h[cc] += x * p[q][cc];
         }
+        // sums over the four 16-lane rows of the wave, two values per exchange: 16 -> 8 -> 4 values per lane
+        double s1[8];
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) part[cc][tid] = h[cc];
+        for (int e = 0; e < 8; ++e) s1[e] = pair_sum32(h[2 * e], h[2 * e + 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pdst[(size_t)(4 * e) * 64] = pair_sum16(s1[2 * e], s1[2 * e + 1]);
         if (tid == c) {
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) prow[c & 1][cc] = p[0][cc];
@@ -79,11 +158,9 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
         __syncthreads();
         {
             const int cq = tid >> 4, ch = tid & 15;
-            double s = 0.0;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s += part[cq][e * 16 + ch];
-            s = row16_sum(s);
-            if (ch == 0) tot[cq] = s;
+            double sv = (part[cq][ch] + part[cq][ch + 16]) + (part[cq][ch + 32] + part[cq][ch + 48]);
+            sv = row16_sum(sv);
+            if (ch == 0) tot[cq] = sv;
         }
         __syncthreads();
         double hs[16], pr[16];
@@ -94,12 +171,8 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
         }
         // ---- dlarfg on (alpha, x)
         const double alpha = pr[c], sigma = hs[c];
-        double tau = 0.0, beta = alpha, scale = 0.0;
-        if (sigma != 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
-        }
+        double tau, beta, scale;
+        house_scalars(alpha, sigma, tau, beta, scale);
         // ---- P[:, c'] -= v w[c'], w[c'] = tau (P[c][c'] + scale h[c'])  (c' > c);  column c <- (beta, v)
 #pragma unroll
         for (int q = 0; q < NROW; ++q) {
@@ -111,14 +184,20 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
             if (i > c) p[q][c] = vi;
             else if (i == c) p[q][c] = beta;
         }
-        // ---- column c of T: T[:c, c] = -tau T[:c, :c] S[:c, c],  S[c'][c] = V[:, c']^T v_c = P[c][c'] + scale h[c']
-        {
-            double acc = 0.0;
+        // ---- column c of S (for T, after the loop): S[c'][c] = V[:, c']^T v_c = P[c][c'] + scale h[c']
+        if (tid < 16) sS[tid][c] = (tid < c) ? pr[tid] + scale * hs[tid] : ((tid == c) ? tau : 0.0);
+    }
+    // ---- T: T[:c, c] = -tau_c T[:c, :c] S[:c, c]; thread r < 16 owns row r
+    __syncthreads();
+    double trow[16];
 #pragma unroll
-            for (int qq = 0; qq < 16; ++qq)
-                if (qq < c) acc += ((qq >= tr) ? trow[qq] : 0.0) * (pr[qq] + scale * hs[qq]);
-            trow[c] = (tr < c) ? -tau * acc : ((tr == c) ? tau : 0.0);
-        }
+    for (int c = 0; c < 16; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq)
+            if (qq < c) acc += ((qq >= tr) ? trow[qq] : 0.0) * sS[qq][c];
+        const double tau = sS[c][c];
+        trow[c] = (tr < c) ? -tau * acc : ((tr == c) ? tau : 0.0);
     }
     // ---- out
 #pragma unroll
@@ -138,33 +217,52 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
     }
 }
 
-// Y = A22 V (m x 16), A22 = A[r0:, r0:] symmetric and fully stored; one workgroup per 16 rows, its four waves split
+// acc += sum over the k steps [ks0, ks1) of A-operand x B-operand, eight k steps of loads in flight at a time (the
+// operands come straight from L2: one load round trip per MFMA would otherwise bound these loops)
+template <class FA, class FB>
+__device__ __forceinline__ void mfma_stream(double4_t &acc, int ks0, int ks1, FA fa, FB fb)
+{
+    for (int ks = ks0; ks < ks1; ks += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = ks + e < ks1;
+            a[e] = in ? fa(ks + e) : 0.0;
+            b[e] = in ? fb(ks + e) : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], b[e], acc, 0, 0, 0);
+    }
+}
+
+// Y = A22 V (m x 16), A22 = A[r0:, r0:] symmetric and fully stored; one workgroup per 16 rows, its eight waves split
 // the contraction; MFMA operands straight from global memory (A22[kk][i] for A22[i][kk]: 128-byte segments; V rows
 // are 512 contiguous bytes per k step).  Also the tile's part of M1 = V^T Y (16 x 16) into M1p[tile].
-__global__ __launch_bounds__(256) void k_sbr_y(const double *__restrict__ A, int lda, int n, int r0, const double *__restrict__ Vbuf,
-                                               double *__restrict__ Ybuf, double *__restrict__ M1p)
+constexpr int SBR_YW = 8;
+__global__ __launch_bounds__(SBR_YW * 64) void k_sbr_y(const double *__restrict__ A, int lda, int n, int r0,
+                                                      const double *__restrict__ Vbuf, double *__restrict__ Ybuf,
+                                                      double *__restrict__ M1p)
 {
-    __shared__ double red[4][4][64];
+    __shared__ double red[SBR_YW][4][64];
     __shared__ double ytile[16][17];
     const int m = n - r0, i0 = blockIdx.x * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-    const int nks = (m + 3) / 4;
+    const int nks = (m + 3) / 4, per = (nks + SBR_YW - 1) / SBR_YW;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     const bool rowok = i0 + lr < m;
-    for (int ks = wave; ks < nks; ks += 4) {
-        const int kk = 4 * ks + lk;
-        const bool ok = kk < m;
-        const double a = (ok && rowok) ? A[(size_t)(r0 + kk) * lda + r0 + i0 + lr] : 0.0;
-        const double b = ok ? Vbuf[(size_t)kk * 16 + lr] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
+    const double *Ab = A + (size_t)r0 * lda + r0 + i0 + lr;
+    mfma_stream(acc, wave * per, min(nks, (wave + 1) * per),
+                [&](int ks) { const int kk = 4 * ks + lk; return (kk < m && rowok) ? Ab[(size_t)kk * lda] : 0.0; },
+                [&](int ks) { const int kk = 4 * ks + lk; return kk < m ? Vbuf[(size_t)kk * 16 + lr] : 0.0; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double y = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+            double y = 0.0;
+#pragma unroll
+            for (int w = 0; w < SBR_YW; ++w) y += red[w][r][lane];
             const int row = lk + 4 * r;                              // accumulator layout: row = lk + 4 r, col = lr
             ytile[row][lr] = y;
             if (i0 + row < m) Ybuf[(size_t)(i0 + row) * 16 + lr] = y;
@@ -183,48 +281,64 @@ __global__ __launch_bounds__(256) void k_sbr_y(const double *__restrict__ A, int
     }
 }
 
-// W = (Y - 1/2 V (T^T M1)) T, one workgroup per 16 rows (M1 = sum of the tile parts, fixed order).
-__global__ __launch_bounds__(256) void k_sbr_w(int m, const double *__restrict__ Vbuf, const double *__restrict__ Ybuf,
-                                               const double *__restrict__ Tbuf, const double *__restrict__ M1p, int ntile,
-                                               double *__restrict__ Wbuf)
-{
-    __shared__ double sT[16][17], sM[16][17], sN[16][17], sX[16][17];
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15, i0 = blockIdx.x * 16;
-    double m1 = 0.0;
-    for (int t = 0; t < ntile; ++t) m1 += M1p[(size_t)t * 256 + tid];
-    sM[r][c] = m1;
-    sT[r][c] = Tbuf[tid];
-    __syncthreads();
-    double nn = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) nn += sT[kk][r] * sM[kk][c];        // (T^T M1)[r][c]
-    sN[r][c] = nn;
-    __syncthreads();
-    const bool ok = i0 + r < m;
-    double x = ok ? Ybuf[(size_t)(i0 + r) * 16 + c] : 0.0;
-    if (ok) {
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) x -= 0.5 * Vbuf[(size_t)(i0 + r) * 16 + kk] * sN[kk][c];
-    }
-    sX[r][c] = x;
-    __syncthreads();
-    double w = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) w += sX[r][kk] * sT[kk][c];
-    if (ok) Wbuf[(size_t)(i0 + r) * 16 + c] = w;
-}
-
-// blocks [0, nt2): A22 <- A22 - V W^T - W V^T on 32 x 32 tiles (4 waves x one 16 x 16 MFMA tile, K = 2 x 16);
+// blocks [0, nt2): A22 <- A22 - V W^T - W V^T on 32 x 32 tiles, W = Y T - V N2, N2 = 1/2 (T^T M1) T (M1 = sum of the
+// tile parts of k_sbr_y, fixed order): every workgroup forms N2 and the 2 x 32 rows of W it needs itself (one more
+// launch per panel would cost more), then 4 waves x one 16 x 16 MFMA tile with K = 2 x 16;
 // blocks [nt2, nt2 + ceil(n/16)): 16 rows of Q:  Q[I, r0:] <- Q[I, r0:] - ((Q[I, r0:] V) T) V^T.
 __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int lda, int n, int r0, const double *__restrict__ Vbuf,
-                                                    const double *__restrict__ Wbuf, const double *__restrict__ Tbuf,
-                                                    double *__restrict__ Q, int ldq, int nt1)
+                                                    const double *__restrict__ Ybuf, const double *__restrict__ Tbuf,
+                                                    const double *__restrict__ M1p, int ntile, double *__restrict__ Q, int ldq, int nt1)
 {
     const int m = n - r0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int nt2 = nt1 * nt1;
+    __shared__ double sT[16][17], sM[16][17], sN[16][17];
+    __shared__ double sW[4][16][17];
+    __shared__ double red[4][4][64];
     if ((int)blockIdx.x < nt2) {
-        const int I = (blockIdx.x / nt1) * 32 + (wave >> 1) * 16, J = (blockIdx.x % nt1) * 32 + (wave & 1) * 16;
+        {
+            const int r = tid >> 4, c = tid & 15;
+            double m1 = 0.0;
+            for (int t = 0; t < ntile; t += 8) {                                // fixed order; eight loads in flight
+                double e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = (t + u < ntile) ? M1p[(size_t)(t + u) * 256 + tid] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m1 += e[u];
+            }
+            sM[r][c] = m1;
+            sT[r][c] = Tbuf[tid];
+            __syncthreads();
+            double nn = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) nn += sT[kk][r] * sM[kk][c];        // (T^T M1)[r][c]
+            sN[r][c] = nn;
+            __syncthreads();
+            double n2 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) n2 += sN[r][kk] * sT[kk][c];
+            sM[r][c] = -0.5 * n2;                                               // -N2
+            __syncthreads();
+        }
+        const int Ib = (blockIdx.x / nt1) * 32, Jb = (blockIdx.x % nt1) * 32;
+        // wave w forms the 16 rows of W starting at R_w = (Ib, Ib+16, Jb, Jb+16)[w]: [Y | V] (16 x 32) x [T ; -N2] (32 x 16)
+        {
+            const int R = (wave < 2 ? Ib : Jb) + (wave & 1) * 16;
+            const bool ok = R + lr < m;
+            double4_t wacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int kk = 4 * s_ + lk;
+                const double y = ok ? Ybuf[(size_t)(R + lr) * 16 + kk] : 0.0, v = ok ? Vbuf[(size_t)(R + lr) * 16 + kk] : 0.0;
+                wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, sT[kk][lr], wacc, 0, 0, 0);
+                wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, sM[kk][lr], wacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sW[wave][lk + 4 * r][lr] = wacc[r];
+        }
+        __syncthreads();
+        const int wi = wave >> 1, wj = wave & 1;                                // tile (I, J) = (Ib + 16 wi, Jb + 16 wj)
+        const int I = Ib + wi * 16, J = Jb + wj * 16;
         if (I >= m || J >= m) return;
         double4_t acc;
 #pragma unroll
@@ -236,10 +350,10 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
             const int kk = 4 * s_ + lk;
-            const double vi = iok ? Vbuf[(size_t)(I + lr) * 16 + kk] : 0.0, wi = iok ? Wbuf[(size_t)(I + lr) * 16 + kk] : 0.0;
-            const double vj = jok ? Vbuf[(size_t)(J + lr) * 16 + kk] : 0.0, wj = jok ? Wbuf[(size_t)(J + lr) * 16 + kk] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, acc, 0, 0, 0);
+            const double vi = iok ? Vbuf[(size_t)(I + lr) * 16 + kk] : 0.0, wi_ = sW[wi][lr][kk];
+            const double vj = jok ? Vbuf[(size_t)(J + lr) * 16 + kk] : 0.0, wj_ = sW[2 + wj][lr][kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj_, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi_, vj, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -249,21 +363,17 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
         return;
     }
     // ---- rows of Q
-    __shared__ double red[4][4][64];
-    __shared__ double zt[16][17];
+    double (*zt)[17] = sN;
     const int I = ((int)blockIdx.x - nt2) * 16;
     const bool rowok = I + lr < n;
     {
         // Z = Q[I, r0:] V: A operand [row = i][k = j] = Q[I+i][r0+j], B operand [k = j][col = c] = V[j][c]
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const int nks = (m + 3) / 4;
-        for (int ks = wave; ks < nks; ks += 4) {
-            const int kk = 4 * ks + lk;
-            const bool ok = kk < m;
-            const double a = (ok && rowok) ? Q[(size_t)(I + lr) * ldq + r0 + kk] : 0.0;
-            const double b = ok ? Vbuf[(size_t)kk * 16 + lr] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
+        const int nks = (m + 3) / 4, per = (nks + 3) / 4;
+        const double *Qb = Q + (size_t)(I + lr) * ldq + r0;
+        mfma_stream(acc, wave * per, min(nks, (wave + 1) * per),
+                    [&](int ks) { const int kk = 4 * ks + lk; return (kk < m && rowok) ? Qb[kk] : 0.0; },
+                    [&](int ks) { const int kk = 4 * ks + lk; return kk < m ? Vbuf[(size_t)kk * 16 + lr] : 0.0; });
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
     }
@@ -336,36 +446,16 @@ __global__ __launch_bounds__(256) void k_set_identity(double *__restrict__ Q, in
 // stage 2
 // ---------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double mk_f64(unsigned lo, unsigned hi) { return __longlong_as_double(((long long)hi << 32) | lo); }
-
-// x + x(lane ^ 16): v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second
-__device__ __forceinline__ double xor16_sum(double x)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
-    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);       // (even row's value) + (odd row's value) in both rows
-}
-
-// x + x(lane ^ 32)
-__device__ __forceinline__ double xor32_sum(double x)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
-    return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);       // (lower half's value) + (upper half's value) in both halves
-}
-
-// sum over the four 16-lane rows of the wave, the same bits in every row
-__device__ __forceinline__ double rows_sum(double x) { return xor32_sum(xor16_sum(x)); }
-
-__device__ __forceinline__ double lane0_f64(double x)
-{
-    const long long b = __double_as_longlong(x);
-    return mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL)), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)));
-}
-
 constexpr int SB2ST_DONE = 1 << 30;
+
+#ifdef JCDF_SB2ST_PROFILE   // diagnostic build (tools/sb2st_prof.py): shader cycles per wave {waiting, in steps, steps, prologues, whole kernel}
+__device__ unsigned long long g_sb2st_prof[16][8];
+#define SB2ST_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SB2ST_ADD(slot, val) do { if (lane == 0) g_sb2st_prof[wave][slot] += (val); } while (0)
+#else
+#define SB2ST_T(var) do { } while (0)
+#define SB2ST_ADD(slot, val) do { } while (0)
+#endif
 
 // Band -> tridiagonal in one workgroup of NW waves.  LDS: band (n + 16) x 32 doubles (16 zero rows behind the matrix:
 // blocks that reach past the end need no masks), NW x 48 doubles of transposition scratch, n progress counters.
@@ -373,18 +463,19 @@ constexpr int SB2ST_DONE = 1 << 30;
 // sums over rows are 4 FMAs + two row exchanges, sums over columns use a second register image of the block with the
 // roles of rows and columns swapped ("layout R": lane = (row lane & 15, columns 4 g + r)) — no 16-lane DPP reduction
 // of four values anywhere.  Vectors change between "indexed by lane & 15" and "indexed by 4 g + r" through 16 doubles of
-// per-wave LDS scratch.
+// per-wave LDS scratch.  The kernel is bound by instruction issue (16 waves on the 4 SIMDs of one CU), so the step is
+// written for instruction count.
 // Sweep s (column s), step t: reflector H_t on rows R_t = s+1+16t .. +15:
 //   D_t <- H_t D_t H_t (symmetric 16 x 16 at R_t), B_t <- B_t H_t (block below it), H_{t+1} from B_t[:, 0], B_t <- H_{t+1} B_t.
 // Step (s, t) may start when step (s-1, t+1) is complete: prog[s-1] >= t+2.
-// log[(s * tmax + t) * 16 + j] = sqrt(tau) v[j]  (H = I - (sqrt(tau) v)(sqrt(tau) v)^T), for k_sb2st_apply_q.
+// vlog[(s * tmax + t) * 16 + j] = v[j] for j >= 1, tau in slot 0 (v[0] = 1), for k_sb2st_apply_q.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restrict__ ABin, int n, double *__restrict__ D,
                                                          double *__restrict__ E, double *__restrict__ vlog, int tmax, int *err)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *band = lds;                                             // (n + 16) * 32
-    double *scr = band + (size_t)(n + 16) * SBW + (threadIdx.x >> 6) * 48;  // per wave: w | z | x
+    double *scr = band + (size_t)(n + 16) * SBW + (threadIdx.x >> 6) * 48;  // per wave: w | tau z | x
     int *prog = (int *)(band + (size_t)(n + 16) * SBW + NW * 48);   // n ints (+1 abort word)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -393,53 +484,56 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
     __syncthreads();
     int *abortw = prog + n;
 
-    int offD[4], offC[4], offR[4];
+    int offD[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * g + r;
         offD[r] = (i >= j) ? j * SBW + (i - j) : i * SBW + (j - i);
-        offC[r] = j * SBW + SB + i - j;                             // B[i][j], layout C
-        const int c = 4 * g + r;                                    // layout R: row = j (lane & 15), column c
-        offR[r] = c * SBW + SB + j - c;
     }
+    const int offC = j * SBW + SB + 4 * g - j;                      // B[4 g + r][j] at offC + r (layout C)
+    const int offR = 4 * g * SBW + SB + j - 4 * g;                  // B[j][4 g + r] at offR + r (SBW - 1) (layout R)
     const int off0 = SB + j;                                        // B[row = lane & 15][0]
+    const bool g0 = g == 0, j0 = j == 0;
 
+    // wave-uniform wait on the sweep in front; false = gave up
     auto wait_for = [&](int s_, int need) -> bool {
         if (s_ < 0) return true;
-        unsigned spins = 0;
-        while (__hip_atomic_load(prog + s_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        for (unsigned spins = 0;; ++spins) {
+            const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (p >= need) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22) || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
-                __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return false;
+            if ((spins & 1023u) == 1023u) {
+                const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (ab != 0 || spins > (1u << 24)) {
+                    __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return false;
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return true;
     };
-    // dlarfg from x given in both index forms; returns v in both forms (v[0] = 1), tau, beta
+    // reflector from x given in both index forms (xj = x[lane & 15], xr[r] = x[4 g + r])
     auto house = [&](double xj, const double (&xr)[4], double &vj, double (&vr)[4], double &tau, double &beta) {
         const double alpha = lane0_f64(xj);
-        double sp = 0.0;
+        const double x0 = g0 ? 0.0 : xr[0];
+        const double sigma = rows_sum(x0 * x0 + xr[1] * xr[1] + xr[2] * xr[2] + xr[3] * xr[3]);
+        double scale;
+        house_scalars(alpha, sigma, tau, beta, scale);
+        vj = j0 ? 1.0 : xj * scale;
+        vr[0] = g0 ? 1.0 : xr[0] * scale;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sp += (4 * g + r >= 1) ? xr[r] * xr[r] : 0.0;
-        const double sigma = rows_sum(sp);
-        double scale = 0.0;
-        tau = 0.0;
-        beta = alpha;
-        if (sigma != 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
-        }
-        vj = (j == 0) ? 1.0 : xj * scale;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vr[r] = (4 * g + r == 0) ? 1.0 : xr[r] * scale;
+        for (int r = 1; r < 4; ++r) vr[r] = xr[r] * scale;
     };
 
     bool alive = true;
+    SB2ST_T(tk0);
     for (int s = wave; s < n - 2 && alive; s += NW) {
         const int nst = (n - s - 3) / SB + 1;
+        SB2ST_T(tw0);
         if (!wait_for(s - 1, 2)) break;
+        SB2ST_T(tw1);
+        SB2ST_ADD(0, tw1 - tw0);
         // ---- reflector that clears column s below the sub-diagonal
         double vj, vr[4], tau, beta;
         {
@@ -449,39 +543,38 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) xr[r] = col[4 * g + r];
             house(xj, xr, vj, vr, tau, beta);
-            if (g == 0) col[j] = (j == 0) ? beta : 0.0;
+            if (g0) col[j] = j0 ? beta : 0.0;
         }
-        int r0 = s + 1;
-        for (int t = 0; t < nst; ++t, r0 += SB) {
+        SB2ST_T(tp1);
+        SB2ST_ADD(3, tp1 - tw1);
+        double *base = band + (size_t)(s + 1) * SBW;
+        double *lg = vlog + (size_t)s * tmax * 16 + j;
+        for (int t = 0; t < nst; ++t, base += SB * SBW, lg += 16) {
+            SB2ST_T(ts0);
             if (t > 0 && !wait_for(s - 1, t + 2)) { alive = false; break; }
-            double *base = band + (size_t)r0 * SBW;
-            if (g == 0) vlog[((size_t)s * tmax + t) * 16 + j] = sqrt(tau) * vj;
+            SB2ST_T(ts1);
+            SB2ST_ADD(0, ts1 - ts0);
             double d[4], bc[4], br[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 d[r] = base[offD[r]];
-                bc[r] = base[offC[r]];
-                br[r] = base[offR[r]];
+                bc[r] = base[offC + r];
+                br[r] = base[offR + r * (SBW - 1)];
             }
             const double b0 = base[off0];
+            if (g0) *lg = j0 ? tau : vj;
             // u[j] = sum_i D[i][j] v[i] (D symmetric), z[row] = sum_c B[row][c] v[c]
-            double up = 0.0, zp = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                up += d[r] * vr[r];
-                zp += br[r] * vr[r];
-            }
-            const double u = rows_sum(up), z = rows_sum(zp);
+            const double u = rows_sum(d[0] * vr[0] + d[1] * vr[1] + d[2] * vr[2] + d[3] * vr[3]);
+            const double z = rows_sum(br[0] * vr[0] + br[1] * vr[1] + br[2] * vr[2] + br[3] * vr[3]);
             const double gamma = row16_sum(u * vj);
-            const double w = tau * u - 0.5 * tau * tau * gamma * vj;
-            const double x = b0 - tau * z;                          // first column of B H (v[0] = 1)
-            if (g == 0) {
+            const double w = tau * (u - (0.5 * tau * gamma) * vj);
+            const double tz = tau * z;
+            const double x = b0 - tz;                               // first column of B H (v[0] = 1)
+            if (g0) {
                 scr[j] = w;
-                scr[16 + j] = z;
+                scr[16 + j] = tz;
                 scr[32 + j] = x;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             double wr[4], zr[4], xr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -489,29 +582,28 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
                 zr[r] = scr[16 + 4 * g + r];
                 xr[r] = scr[32 + 4 * g + r];
             }
-            // D <- D - v w^T - w v^T (lower triangle goes back)
+            // D <- D - v w^T - w v^T: (v_i w_j) + (w_i v_j) is the same number in the lanes of (i, j) and (j, i), both store
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d[r] -= vr[r] * w + wr[r] * vj;
-                if (4 * g + r >= j) base[offD[r]] = d[r];
-            }
+            for (int r = 0; r < 4; ++r) base[offD[r]] = d[r] - __dadd_rn(__dmul_rn(vr[r], w), __dmul_rn(wr[r], vj));   // (no fma: it would break the symmetry)
             // B <- B - tau z v^T
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bc[r] -= tau * zr[r] * vj;
+            for (int r = 0; r < 4; ++r) bc[r] -= zr[r] * vj;
             // next reflector from the first column x of B
             double v2j, v2r[4], tau2, beta2;
             house(x, xr, v2j, v2r, tau2, beta2);
-            double gp = 0.0;
+            const double tg = tau2 * rows_sum(v2r[0] * bc[0] + v2r[1] * bc[1] + v2r[2] * bc[2] + v2r[3] * bc[3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gp += v2r[r] * bc[r];
-            const double gg = rows_sum(gp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bc[r] -= tau2 * v2r[r] * gg;
-                if (j == 0) bc[r] = (4 * g + r == 0) ? beta2 : 0.0;
-                base[offC[r]] = bc[r];
+            for (int r = 0; r < 4; ++r) bc[r] -= v2r[r] * tg;
+            if (j0) {
+                bc[0] = g0 ? beta2 : 0.0;
+                bc[1] = bc[2] = bc[3] = 0.0;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[offC + r] = bc[r];
             __hip_atomic_store(prog + s, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            SB2ST_T(ts2);
+            SB2ST_ADD(1, ts2 - ts1);
+            SB2ST_ADD(2, 1ULL);
             vj = v2j;
             tau = tau2;
 #pragma unroll
@@ -519,6 +611,8 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
         }
         __hip_atomic_store(prog + s, SB2ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    SB2ST_T(tk1);
+    SB2ST_ADD(4, tk1 - tk0);
     __syncthreads();
     if (tid == 0 && *abortw != 0) *err = 2;
     for (int i = tid; i < n; i += NW * 64) {
@@ -527,58 +621,68 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
     }
 }
 
-// Q <- Q H_(0,0) H_(0,1) ... H_(1,0) ... (the order of the sequential algorithm) on 4 RPL rows per wave, rows in LDS.
-// Lane = (column j of the 16-wide window, row group); consecutive steps of one sweep touch disjoint windows.
-template <int RPL>
-__global__ __launch_bounds__(256) void k_sb2st_apply_q(double *__restrict__ Q, int ldq, int n, const double *__restrict__ vlog, int tmax)
+// Q <- Q H_(0,0) H_(0,1) ... H_(1,0) ... (the order of the sequential algorithm): ONE ROW of Q per wave, in LDS.  The steps
+// of one sweep touch disjoint 16-column windows, so the four 16-lane rows of the wave take four consecutive steps of
+// the sweep at once: lane l works on column s + 1 + 64 grp + l with the log entry at the same offset — every access is
+// 64 consecutive doubles.  n waves of 2 n^2 / 64 wave-instructions each (a wave with four rows and one step per
+// instruction — 4 x fewer, 4 x longer waves — took 1.03 ms at n = 510).
+// The log entries of sweep s + 1 are fetched (MAXG loads per lane) while sweep s is applied, and the MAXG groups of a sweep
+// are independent chains: neither the L2 latency of the log nor the LDS round trip of a window is paid per group.
+template <int NWQ, int MAXG>
+__global__ __launch_bounds__(NWQ * 64) void k_sb2st_apply_q(double *__restrict__ Q, int ldq, int n, const double *__restrict__ vlog,
+                                                           int tmax)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int ldr = n + 17;                                        // 16 zero columns behind every row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-    const int rows_wg = 16 * RPL, row0 = blockIdx.x * rows_wg;
-    for (int idx = tid; idx < rows_wg * ldr; idx += 256) {
-        const int r = idx / ldr, c = idx % ldr;
-        lds[idx] = (row0 + r < n && c < n) ? Q[(size_t)(row0 + r) * ldq + c] : 0.0;
-    }
-    __syncthreads();
-    double *myrow[RPL];
+    const int ldr = n + 144;                                       // 80 zero columns behind the row + 64 of scratch for idle groups
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x * NWQ + wave;
+    if (row >= n) return;
+    double *q = lds + (size_t)wave * ldr;
+    for (int c = lane; c < ldr; c += 64) q[c] = c < n ? Q[(size_t)row * ldq + c] : 0.0;
+    const bool j0 = (lane & 15) == 0;
+    const int dummy = n + 80 + lane;
+    auto fetch = [&](int s, double (&v)[MAXG]) {
+        const int nst = (s < n - 2) ? (n - s - 3) / SB + 1 : 0;
+        const double *vl = vlog + (size_t)s * tmax * 16 + lane;
 #pragma unroll
-    for (int e = 0; e < RPL; ++e) myrow[e] = lds + (size_t)(wave * 4 * RPL + 4 * e + g) * ldr + j;
+        for (int e = 0; e < MAXG; ++e) v[e] = (4 * e + (lane >> 4) < nst) ? vl[64 * e] : 0.0;   // steps past the end: H = I
+    };
+    // G groups of the current sweep: G independent chains (read window, 16-lane dot product, update, write back)
+    auto apply = [&](auto G_, int s, int nst, const double (&v)[MAXG]) {
+        constexpr int G = decltype(G_)::value;
+        int idx[G];
+        double x[G];
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            idx[e] = (4 * e < nst) ? s + 1 + 64 * e + lane : dummy;
+            x[e] = q[idx[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            const double tau = dpp_f64<0x150, 0xf>(v[e]);                  // row_newbcast:0 — slot 0 of an entry holds tau
+            const double ve = j0 ? 1.0 : v[e];
+            const double dt = tau * row16_sum(x[e] * ve);
+            q[idx[e]] = x[e] - dt * ve;
+        }
+    };
+    double v0[MAXG], v1[MAXG], v2[MAXG], v3[MAXG];                         // the log three sweeps ahead (L2 latency ~ 1 us)
+    fetch(0, v0);
+    fetch(1, v1);
+    fetch(2, v2);
     for (int s = 0; s < n - 2; ++s) {
+        fetch(s + 3, v3);
         const int nst = (n - s - 3) / SB + 1;
-        const double *vl = vlog + (size_t)s * tmax * 16 + j;
-        int c0 = s + 1;
-        int t = 0;
-        for (; t + 2 <= nst; t += 2, c0 += 2 * SB) {
-            const double va = vl[(size_t)t * 16], vb = vl[(size_t)(t + 1) * 16];
-            double qa[RPL], qb[RPL];
+        if (nst > 24) apply(std::integral_constant<int, MAXG>(), s, nst, v0);
+        else if (nst > 12) apply(std::integral_constant<int, 6>(), s, nst, v0);
+        else apply(std::integral_constant<int, 3>(), s, nst, v0);
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-                qa[e] = myrow[e][c0];
-                qb[e] = myrow[e][c0 + SB];
-            }
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-                const double da = row16_sum(qa[e] * va), db = row16_sum(qb[e] * vb);
-                myrow[e][c0] = qa[e] - da * va;
-                myrow[e][c0 + SB] = qb[e] - db * vb;
-            }
-        }
-        if (t < nst) {
-            const double va = vl[(size_t)t * 16];
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-                const double qa = myrow[e][c0];
-                const double da = row16_sum(qa * va);
-                myrow[e][c0] = qa - da * va;
-            }
+        for (int e = 0; e < MAXG; ++e) {
+            v0[e] = v1[e];
+            v1[e] = v2[e];
+            v2[e] = v3[e];
         }
     }
-    __syncthreads();
-    for (int idx = tid; idx < rows_wg * n; idx += 256) {
-        const int r = idx / n, c = idx % n;
-        if (row0 + r < n) Q[(size_t)(row0 + r) * ldq + c] = lds[(size_t)r * ldr + c];
-    }
+    for (int c = lane; c < n; c += 64) Q[(size_t)row * ldq + c] = q[c];
 }
 
 }  // namespace jcdf
