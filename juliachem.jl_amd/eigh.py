@@ -22,6 +22,7 @@ import torch
 
 from . import _lib
 
+TWO_STAGE_DEFAULT = False     # flipped once the two-stage path is the faster one on the bench shape
 _EVECT_TRIDIAGONAL = 212      # rocblas_evect_tridiagonal
 _SIDE_LEFT = 141              # rocblas_side_left
 _FILL_LOWER = 122             # rocblas_fill_lower
@@ -61,6 +62,17 @@ class DeviceEigh:
             self.Zt = torch.zeros((self.npad, self.npad), **f64)
             self.Up = torch.zeros((self.npad, self.npad), **f64)
             self.own_stedc = not os.environ.get("JCDF_EIGH_VENDOR_STEDC")
+            # two-stage reduction (dense -> band -> tridiagonal, csrc/jcdf_sbr.hpp) where the band fits the LDS of one CU;
+            # its Q replay runs on a side stream beside the tridiagonal solver.  JCDF_EIGH_TWO_STAGE=0/1 overrides.
+            ts = os.environ.get("JCDF_EIGH_TWO_STAGE")
+            self.two_stage = (self.with_q and self.own_stedc and 3 <= n <= int(self.lib.jcdf_sytrd2_max_n())
+                              and (ts == "1" if ts is not None else TWO_STAGE_DEFAULT))
+            if self.two_stage:
+                self.wb2 = int(self.lib.jcdf_sytrd2_workspace_bytes(n))
+                self.work2 = torch.zeros(self.wb2 // 8 + 8, **f64)
+                self.side = torch.cuda.Stream(device=device)
+                self.ev_fork = torch.cuda.Event()
+                self.ev_join = torch.cuda.Event()
             if self.own_stedc:
                 self.dc_wb = int(self.lib.jcdf_stedc_workspace_bytes(n))
                 if self.dc_wb < 0:
@@ -82,6 +94,8 @@ class DeviceEigh:
         self.rb.rocblas_set_stream(self.handle, C.c_void_p(st))
         self.A.copy_(Fp)
         p = lambda t: C.c_void_p(t.data_ptr())
+        if self.two_stage:
+            return self._two_stage(Fp, st, p)
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
                                           p(self.Q) if self.with_q else None, p(self.work), self.wb)
         own_gemm = self.with_q and self.own_stedc
@@ -114,26 +128,55 @@ class DeviceEigh:
         # column-major eigenvector matrix == transpose of the row-major view
         return self.D, self.Cm.T
 
+    def _two_stage(self, Fp, st, p):
+        n, npad = self.n, self.npad
+        main = torch.cuda.current_stream(self.device)
+        # Q (stage 1) straight into the zero padded operand of the back-transformation GEMM
+        rc = self.lib.jcdf_sytrd2_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.Qp), npad, p(self.work2),
+                                         self.wb2)
+        if rc == 0:
+            self.ev_fork.record(main)
+            self.side.wait_event(self.ev_fork)
+            rc = self.lib.jcdf_sytrd2_apply_q_device(C.c_void_p(self.side.cuda_stream), n, p(self.Qp), npad, p(self.work2), self.wb2)
+            self.ev_join.record(self.side)
+        if rc == 0:
+            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(self.Zt), npad, p(self.dc_work), self.dc_wb)
+        main.wait_event(self.ev_join)
+        if rc == 0:
+            rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), npad, npad, npad, p(self.Qp), npad, p(self.Zt), npad, p(self.Up), npad)
+        if rc != 0:
+            self.ok = False
+            self.reason = "library call failed rc=%d (two-stage reduction)" % rc
+            self.fallbacks += 1
+            return torch.linalg.eigh(Fp)
+        self.U_padded = self.Up
+        return self.D, self.Up[:n, :n]
+
+    def _err_word(self) -> torch.Tensor:
+        """1-element int32 view of the error word of the reduction in use"""
+        w = self.work2 if self.two_stage else self.work
+        return w[1:2].view(torch.int32)[0:1]
+
     def status(self) -> torch.Tensor:
         """0-d float64 device tensor, non-zero iff the last call failed (hand-off timeout in the tridiagonalisation or
         a vendor stedc failure) — for callers that fold it into a device-to-host copy they make anyway."""
         if not self.ok:
             return torch.zeros((), dtype=torch.float64, device=self.device)
-        return (self.work[1:2].view(torch.int32)[0].abs() + self.info[0].abs()).to(torch.float64)
+        return (self._err_word()[0].abs() + self.info[0].abs()).to(torch.float64)
 
     def status_tensors(self):
         """(int32 error word of the tridiagonalisation, int32 info of a vendor stedc) as 1-element device views, or
         (None, None) when the plain torch path is in use — for `jcdf_scf_tail_device`."""
         if not self.ok:
             return None, None
-        return self.work[1:2].view(torch.int32)[0:1], self.info
+        return self._err_word(), self.info
 
     def check(self) -> bool:
         """True if the persistent kernel's grid barrier never timed out and stedc converged
         (reads two words from the device: call where the stream is synchronised anyway)."""
         if not self.ok:
             return True
-        err = int(self.work[1:2].view(torch.int32)[0].item())       # int at byte offset 8
+        err = int(self._err_word()[0].item())                       # int at byte offset 8
         bad = err != 0 or int(self.info.item()) != 0
         if bad:
             self.ok = False

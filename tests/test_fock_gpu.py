@@ -398,6 +398,68 @@ def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
 
 
+@pytest.mark.parametrize("n", [3, 4, 5, 17, 18, 19, 33, 34, 64, 100, 130, 257, 510, 590])
+def test_two_stage_tridiagonalisation_matches_numpy(n):
+    """csrc/jcdf_sbr.hpp through the C ABI: dense -> band (16) -> tridiagonal with Q = Q1 Q2 accumulated forwards;
+    A = Q T Q^T, Q orthogonal, spectrum of T = spectrum of A (numpy / LAPACK)."""
+    import ctypes as C
+    import torch
+    lib = jc._lib.load()
+    assert n <= lib.jcdf_sytrd2_max_n()
+    rng = np.random.default_rng(100 + n)
+    A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
+    if n == 64:                                   # degenerate spectrum, zero columns (tau == 0 branches in both stages)
+        A = np.diag(np.repeat(np.arange(8.0), 8)); A[0, 1] = A[1, 0] = 0.5; A[40, 3] = A[3, 40] = -0.25
+    if n == 130:                                  # already banded: stage 1 meets panels that are upper triangular
+        A = np.triu(np.tril(A, 7), -7)
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    dA = torch.as_tensor(A, device=dev).clone()
+    wb = int(lib.jcdf_sytrd2_workspace_bytes(n))
+    work = torch.zeros(wb // 8 + 8, **f64)
+    D = torch.zeros(n, **f64); E = torch.zeros(n, **f64); Q = torch.zeros((n, n), **f64)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.jcdf_sytrd2_device(st, n, p(dA), n, p(D), p(E), p(Q), n, p(work), wb) == 0
+    assert lib.jcdf_sytrd2_apply_q_device(st, n, p(Q), n, p(work), wb) == 0
+    torch.cuda.synchronize()
+    assert int(work[1:2].view(torch.int32)[0].item()) == 0
+    Qh, Dh, Eh = Q.cpu().numpy(), D.cpu().numpy(), E.cpu().numpy()[: n - 1]
+    T = np.diag(Dh) + np.diag(Eh, 1) + np.diag(Eh, -1)
+    scale = max(1.0, np.abs(A).max())
+    assert np.abs(Qh.T @ Qh - np.eye(n)).max() < 1e-13 * n
+    assert np.abs(Qh.T @ A @ Qh - T).max() < 1e-13 * n * scale
+    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A)).max() < 1e-13 * n * scale
+    # argument checks
+    assert lib.jcdf_sytrd2_device(st, int(lib.jcdf_sytrd2_max_n()) + 1, p(dA), n, p(D), p(E), p(Q), n, p(work), wb) != 0
+    assert lib.jcdf_sytrd2_device(st, n, p(dA), n, p(D), p(E), p(Q), n, p(work), wb - 8) != 0
+
+
+@pytest.mark.parametrize("n", [3, 25, 64, 130, 257, 510, 590])
+def test_device_eigh_two_stage_matches_lapack(n, monkeypatch):
+    """DeviceEigh with the two-stage reduction (Q replay on a side stream beside the divide & conquer) vs numpy eigh."""
+    import torch
+    from juliachem_jl_amd.eigh import DeviceEigh
+    monkeypatch.setenv("JCDF_EIGH_TWO_STAGE", "1")
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
+    if n == 64:
+        A = np.diag(np.repeat(np.arange(8.0), 8)); A[0, 1] = A[1, 0] = 0.5
+    dev = torch.device("cuda", 0)
+    eg = DeviceEigh(n, dev)
+    assert eg.ok and eg.two_stage, getattr(eg, "reason", "")
+    for rep in range(2):                          # twice: workspace and side-stream state are reusable
+        w, U = eg(torch.as_tensor(A, device=dev))
+        torch.cuda.synchronize()
+        assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")
+        w = w.cpu().numpy().copy(); U = U.cpu().numpy().copy()
+        wref = np.linalg.eigvalsh(A)
+        scale = max(1.0, np.abs(wref).max())
+        assert np.abs(w - wref).max() < 1e-12 * scale * n
+        assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
+        assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
+
+
 def test_operator_with_two_devices_in_one_process(monkeypatch):
     """num_devices = 2 (the reference's one-rank-many-GPUs mode, GPUDF.jl:188-277): two handles,
     two aux shards, concurrent begin/finish, host reduce — wrapped onto the one physical GPU."""
