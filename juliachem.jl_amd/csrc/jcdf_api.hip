@@ -1365,6 +1365,15 @@ Sytrd2Layout sytrd2_layout(int64_t n)
 }
 constexpr int SB2ST_WAVES = 16;
 size_t sb2st_lds(int64_t n) { return (size_t)(n + 16) * SBW * 8 + SB2ST_WAVES * 48 * 8 + (size_t)(n + 2) * 4; }
+size_t sb2st3_lds(int64_t n)
+{
+    return (size_t)(n + 16) * SBW * 8 + (size_t)16 * 48 * 8 + (size_t)8 * 4 * SB2ST_MBOX * 8 + (size_t)(n + 2 + 8) * 4;
+}
+constexpr int SB2ST_PAIRS = 8, SB2ST_RING = 4;
+size_t sb2st2_lds(int64_t n)
+{
+    return (size_t)(n + 16) * SBW * 8 + (size_t)SB2ST_PAIRS * SB2ST_RING * SB2ST_SLOT * 8 + (size_t)(n + 2 + 2 * SB2ST_PAIRS) * 4;
+}
 }  // namespace
 
 int64_t jcdf_sytrd2_max_n(void)
@@ -1408,10 +1417,37 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
                            T, M1p, ntile, d_Q, (int)ldq, nt1);
     }
     hipLaunchKernelGGL(k_sbr_extract, dim3((unsigned)((n * SBW + 255) / 256)), dim3(256), 0, st, d_A, (int)lda, ni, AB);
-    const size_t lds = sb2st_lds(n);
-    if (hipFuncSetAttribute((const void *)k_sb2st_chase<SB2ST_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return JCDF_ERR_HIP;
-    hipLaunchKernelGGL(k_sb2st_chase<SB2ST_WAVES>, dim3(1), dim3(SB2ST_WAVES * 64), lds, st, AB, ni, d_D, d_E, vlog, (int)L.tmax, err);
+    // two waves per sweep (chain + update) where the ring fits beside the band; JCDF_SB2ST_ONE_WAVE=1: the one-wave kernel
+    static const int variant = getenv("JCDF_SB2ST_VARIANT") ? atoi(getenv("JCDF_SB2ST_VARIANT")) : 1;   // 1: one wave per sweep (fastest measured), 2: chain + update waves, 3: ping-pong
+    const bool one_wave = variant == 1;
+    if (variant == 3 && sb2st3_lds(n) <= 160 * 1024) {
+        const size_t lds = sb2st3_lds(n);
+        if (hipFuncSetAttribute((const void *)k_sb2st_chase3<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return JCDF_ERR_HIP;
+        hipLaunchKernelGGL(k_sb2st_chase3<8>, dim3(1), dim3(8 * 128), lds, st, AB, ni, d_D, d_E, vlog, (int)L.tmax, err);
+    } else if (!one_wave && sb2st2_lds(n) <= 160 * 1024) {
+        const size_t lds = sb2st2_lds(n);
+        if (hipFuncSetAttribute((const void *)k_sb2st_chase2<SB2ST_PAIRS, SB2ST_RING>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return JCDF_ERR_HIP;
+        hipLaunchKernelGGL((k_sb2st_chase2<SB2ST_PAIRS, SB2ST_RING>), dim3(1), dim3(SB2ST_PAIRS * 128), lds, st, AB, ni, d_D, d_E, vlog,
+                           (int)L.tmax, err);
+    } else {
+        const size_t lds = sb2st_lds(n);
+        static const int nw = getenv("JCDF_SB2ST_NW") ? atoi(getenv("JCDF_SB2ST_NW")) : SB2ST_WAVES;    // experiments only
+#define JCDF_CHASE1(NW_)                                                                                                         \
+    do {                                                                                                                         \
+        if (hipFuncSetAttribute((const void *)k_sb2st_chase<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return JCDF_ERR_HIP;                                                                                                 \
+        hipLaunchKernelGGL(k_sb2st_chase<NW_>, dim3(1), dim3(NW_ * 64), lds, st, AB, ni, d_D, d_E, vlog, (int)L.tmax, err);      \
+    } while (0)
+        if (nw == 1) JCDF_CHASE1(1);
+        else if (nw == 2) JCDF_CHASE1(2);
+        else if (nw == 4) JCDF_CHASE1(4);
+        else if (nw == 8) JCDF_CHASE1(8);
+        else JCDF_CHASE1(16);
+#undef JCDF_CHASE1
+    }
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

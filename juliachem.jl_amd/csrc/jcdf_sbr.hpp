@@ -402,24 +402,30 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_) za[s_] = -zt[lr][4 * s_ + lk];
     const int ntj = (m + 15) / 16;
-    for (int tj = wave; tj < ntj; tj += 4) {
-        const int J = tj * 16;
-        double4_t acc;
+    for (int tj0 = wave; tj0 < ntj; tj0 += 16) {                  // four column tiles of this wave at a time: their loads overlap
+        double4_t acc[4];
+        double b[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = I + lk + 4 * r, col = J + lr;
-            acc[r] = (row < n && col < m) ? Q[(size_t)row * ldq + r0 + col] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const int J = (tj0 + 4 * u) * 16;
+            const bool jok = J + lr < m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I + lk + 4 * r, col = J + lr;
+                acc[u][r] = (row < n && col < m) ? Q[(size_t)row * ldq + r0 + col] : 0.0;
+                b[u][r] = jok ? Vbuf[(size_t)(J + lr) * 16 + 4 * r + lk] : 0.0;
+            }
         }
-        const bool jok = J + lr < m;
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            const double b = jok ? Vbuf[(size_t)(J + lr) * 16 + 4 * s_ + lk] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[s_], b, acc, 0, 0, 0);
-        }
+        for (int u = 0; u < 4; ++u) {
+            const int J = (tj0 + 4 * u) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = I + lk + 4 * r, col = J + lr;
-            if (row < n && col < m) Q[(size_t)row * ldq + r0 + col] = acc[r];
+            for (int s_ = 0; s_ < 4; ++s_) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[s_], b[u][s_], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I + lk + 4 * r, col = J + lr;
+                if (row < n && col < m) Q[(size_t)row * ldq + r0 + col] = acc[u][r];
+            }
         }
     }
 }
@@ -616,6 +622,380 @@ __global__ __launch_bounds__(NW * 64) void k_sb2st_chase(const double *__restric
     __syncthreads();
     if (tid == 0 && *abortw != 0) *err = 2;
     for (int i = tid; i < n; i += NW * 64) {
+        D[i] = band[(size_t)i * SBW];
+        if (i < n - 1) E[i] = band[(size_t)i * SBW + 1];
+    }
+}
+
+// ---- the same chase with TWO waves per sweep ---------------------------------------------------------------------------
+// The time of k_sb2st_chase is the dependency chain "step (s, t+1) complete -> step (s+1, t) may start", 2 n steps long,
+// each step one wave's ~250 dependent-ish instructions (~2000 cycles; the waves wait two thirds of the time).  Only the
+// reflector chain of a sweep is sequential inside the sweep:  v_t -> z = B_t v_t -> x = B_t[:, 0] - tau z -> v_{t+1};
+// the updates of D_t and B_t are needed by the NEXT sweep, not by the next step.  So a sweep is run by a pair of waves:
+//   C (chain):  waits for the sweep in front, reads B_t once (layout R), forms z, x and the next reflector, and passes
+//               {v, tau z, x, tau, tau', scale', beta'} to its partner through a small ring in LDS — it never waits for
+//               its partner's updates (only for ring space);
+//   U (update): D_t <- H D_t H,  B_t <- H' (B_t H), stores the blocks and publishes the progress counter of the sweep.
+// A sweep now trails the one in front by 2 max(C, U) instead of 2 (C + U).
+constexpr int SB2ST_SLOT = 72;       // doubles per ring slot: v[16] | tau z[16] | x[16] | w[16] (U's own) | tau, tau', scale', beta', ...
+template <int NP, int RING>
+__global__ __launch_bounds__(NP * 128) void k_sb2st_chase2(const double *__restrict__ ABin, int n, double *__restrict__ D,
+                                                           double *__restrict__ E, double *__restrict__ vlog, int tmax, int *err)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *band = lds;                                             // (n + 16) * 32
+    double *ringbase = band + (size_t)(n + 16) * SBW;               // NP * RING * SB2ST_SLOT
+    int *prog = (int *)(ringbase + NP * RING * SB2ST_SLOT);         // n progress counters, abort word, 2 NP sequence counters
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave >> 1;
+    const bool is_c = (wave & 1) == 0;
+    const int j = lane & 15, g = lane >> 4;
+    for (int i = tid; i < (n + 16) * SBW; i += NP * 128) band[i] = (i < n * SBW) ? ABin[i] : 0.0;
+    for (int i = tid; i < n + 1 + 2 * NP; i += NP * 128) prog[i] = 0;
+    __syncthreads();
+    int *abortw = prog + n, *cseq = prog + n + 1 + pair, *useq = prog + n + 1 + NP + pair;
+    double *ring = ringbase + (size_t)pair * RING * SB2ST_SLOT;
+    const bool g0 = g == 0, j0 = j == 0;
+
+    // wave-uniform wait until *word >= need; false = gave up
+    auto wait_ge = [&](const int *word, int need) -> bool {
+        for (unsigned spins = 0;; ++spins) {
+            const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (p >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 1023u) == 1023u) {
+                const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (ab != 0 || spins > (1u << 24)) {
+                    __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return false;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    };
+
+    int seq = 0;                                                    // steps of this pair so far (both waves count alike)
+    SB2ST_T(tk0);
+    if (is_c) {
+        const int offR = 4 * g * SBW + SB + j - 4 * g;              // B[j][4 g + r] at offR + r (SBW - 1) (layout R)
+        const int off0 = SB + j;                                    // B[row = lane & 15][0]
+        bool alive = true;
+        for (int s = pair; s < n - 2 && alive; s += NP) {
+            const int nst = (n - s - 3) / SB + 1;
+            if (s > 0 && !wait_ge(prog + s - 1, 2)) break;
+            // ---- reflector that clears column s below the sub-diagonal
+            double vj, vr[4], tau;
+            {
+                double *col = band + (size_t)s * SBW + 1;
+                const double xj = col[j];
+                double xr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r] = col[4 * g + r];
+                const double alpha = lane0_f64(xj);
+                const double x0 = g0 ? 0.0 : xr[0];
+                const double sigma = rows_sum(x0 * x0 + xr[1] * xr[1] + xr[2] * xr[2] + xr[3] * xr[3]);
+                double beta, scale;
+                house_scalars(alpha, sigma, tau, beta, scale);
+                vj = j0 ? 1.0 : xj * scale;
+                vr[0] = g0 ? 1.0 : xr[0] * scale;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) vr[r] = xr[r] * scale;
+                if (g0) col[j] = j0 ? beta : 0.0;
+            }
+            const double *base = band + (size_t)(s + 1) * SBW;
+            double *lg = vlog + (size_t)s * tmax * 16 + j;
+            for (int t = 0; t < nst; ++t, base += SB * SBW, lg += 16, ++seq) {
+                SB2ST_T(tc0);
+                if (t > 0 && s > 0 && !wait_ge(prog + s - 1, t + 2)) { alive = false; break; }
+                SB2ST_T(tc1);
+                SB2ST_ADD(0, tc1 - tc0);
+                double br[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) br[r] = base[offR + r * (SBW - 1)];
+                const double b0 = base[off0];
+                if (g0) *lg = j0 ? tau : vj;
+                const double tz = tau * rows_sum(br[0] * vr[0] + br[1] * vr[1] + br[2] * vr[2] + br[3] * vr[3]);
+                const double x = b0 - tz;                           // first column of B H (v[0] = 1), indexed by lane & 15
+                SB2ST_T(tc2);
+                if (seq >= RING && !wait_ge(useq, seq - RING + 1)) { alive = false; break; }
+                SB2ST_T(tc3);
+                SB2ST_ADD(5, tc3 - tc2);
+                double *slot = ring + (size_t)(seq % RING) * SB2ST_SLOT;
+                if (g0) {
+                    slot[j] = vj;
+                    slot[16 + j] = tz;
+                    slot[32 + j] = x;
+                }
+                double xr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r] = slot[32 + 4 * g + r];
+                const double alpha = lane0_f64(x);
+                const double sigma = row16_sum(j0 ? 0.0 : x * x);
+                double tau2, beta2, scale2;
+                house_scalars(alpha, sigma, tau2, beta2, scale2);
+                if (lane == 0) {
+                    slot[64] = tau;
+                    slot[65] = tau2;
+                    slot[66] = scale2;
+                    slot[67] = beta2;
+                }
+                __hip_atomic_store(cseq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                SB2ST_T(tc4);
+                SB2ST_ADD(1, (tc4 - tc1) - (tc3 - tc2));
+                SB2ST_ADD(2, 1ULL);
+                vj = j0 ? 1.0 : x * scale2;
+                vr[0] = g0 ? 1.0 : xr[0] * scale2;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) vr[r] = xr[r] * scale2;
+                tau = tau2;
+            }
+        }
+    } else {
+        int offD[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r;
+            offD[r] = (i >= j) ? j * SBW + (i - j) : i * SBW + (j - i);
+        }
+        const int offC = j * SBW + SB + 4 * g - j;                  // B[4 g + r][j] at offC + r (layout C)
+        bool alive = true;
+        for (int s = pair; s < n - 2 && alive; s += NP) {
+            const int nst = (n - s - 3) / SB + 1;
+            double *base = band + (size_t)(s + 1) * SBW;
+            for (int t = 0; t < nst; ++t, base += SB * SBW, ++seq) {
+                SB2ST_T(tu0);
+                if (!wait_ge(cseq, seq + 1)) { alive = false; break; }
+                SB2ST_T(tu1);
+                SB2ST_ADD(0, tu1 - tu0);
+                double *slot = ring + (size_t)(seq % RING) * SB2ST_SLOT;
+                const double vj = slot[j], tzj = slot[16 + j];
+                double vr[4], tzr[4], xr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vr[r] = slot[4 * g + r];
+                    tzr[r] = slot[16 + 4 * g + r];
+                    xr[r] = slot[32 + 4 * g + r];
+                }
+                const double tau = slot[64], tau2 = slot[65], scale2 = slot[66], beta2 = slot[67];
+                double d[4], bc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d[r] = base[offD[r]];
+                    bc[r] = base[offC + r];
+                }
+                // D <- H D H: u = D v (D symmetric: column sums), gamma = v^T u, w = tau u - (tau^2 gamma / 2) v
+                const double u = rows_sum(d[0] * vr[0] + d[1] * vr[1] + d[2] * vr[2] + d[3] * vr[3]);
+                const double gamma = row16_sum(u * vj);
+                const double w = tau * (u - (0.5 * tau * gamma) * vj);
+                if (g0) slot[48 + j] = w;
+                // B <- B - (tau z) v^T, then H' from the left: B <- B - v' (tau' v'^T B), first column (beta', 0, ...)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bc[r] -= tzr[r] * vj;
+                double v2r[4];
+                v2r[0] = g0 ? 1.0 : xr[0] * scale2;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v2r[r] = xr[r] * scale2;
+                const double tg = tau2 * rows_sum(v2r[0] * bc[0] + v2r[1] * bc[1] + v2r[2] * bc[2] + v2r[3] * bc[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bc[r] -= v2r[r] * tg;
+                if (j0) {
+                    bc[0] = g0 ? beta2 : 0.0;
+                    bc[1] = bc[2] = bc[3] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) base[offC + r] = bc[r];
+                double wr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wr[r] = slot[48 + 4 * g + r];
+                // (v_i w_j) + (w_i v_j) is the same number in the lanes of (i, j) and (j, i): both store (no fma: symmetry)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) base[offD[r]] = d[r] - __dadd_rn(__dmul_rn(vr[r], w), __dmul_rn(wr[r], vj));
+                __hip_atomic_store(prog + s, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(useq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                SB2ST_T(tu2);
+                SB2ST_ADD(1, tu2 - tu1);
+                SB2ST_ADD(2, 1ULL);
+                (void)tzj;
+            }
+            if (alive) __hip_atomic_store(prog + s, SB2ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    SB2ST_T(tk1);
+    SB2ST_ADD(4, tk1 - tk0);
+    __syncthreads();
+    if (tid == 0 && *abortw != 0) *err = 2;
+    for (int i = tid; i < n; i += NP * 128) {
+        D[i] = band[(size_t)i * SBW];
+        if (i < n - 1) E[i] = band[(size_t)i * SBW + 1];
+    }
+}
+
+// ---- two waves per sweep, taking its steps in turn ("ping-pong") ---------------------------------------------------------
+// Step t+1 of a sweep needs from step t only the next reflector, which is known a third of the way into the step (after
+// z = B v, x and the dlarfg scalars); the rest of step t (the updates of D_t and B_t and their stores) is needed by the NEXT
+// sweep.  So the steps of a sweep alternate between the two waves of a pair: a wave publishes v_{t+1} through a 17-double
+// mailbox in LDS as soon as it has it, and its partner starts step t+1 while it finishes step t.  Both waves run the same
+// code; a sweep now advances one step per max(chain part + hand-off, step / 2).  Progress counters stay ordered: the wave
+// of step t publishes t+1 only after it has seen t.
+constexpr int SB2ST_MBOX = 24;       // doubles per mailbox slot: v[16] | tau
+template <int NP>
+__global__ __launch_bounds__(NP * 128) void k_sb2st_chase3(const double *__restrict__ ABin, int n, double *__restrict__ D,
+                                                           double *__restrict__ E, double *__restrict__ vlog, int tmax, int *err)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int RING = 4;
+    double *band = lds;                                             // (n + 16) * 32
+    double *scr = band + (size_t)(n + 16) * SBW + (threadIdx.x >> 6) * 48;   // per wave: w | tau z | x
+    double *mbase = band + (size_t)(n + 16) * SBW + 2 * NP * 48;    // NP * RING * SB2ST_MBOX
+    int *prog = (int *)(mbase + NP * RING * SB2ST_MBOX);            // n progress counters, abort word, NP mailbox counters
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave >> 1, me = wave & 1;
+    const int j = lane & 15, g = lane >> 4;
+    for (int i = tid; i < (n + 16) * SBW; i += NP * 128) band[i] = (i < n * SBW) ? ABin[i] : 0.0;
+    for (int i = tid; i < n + 1 + NP; i += NP * 128) prog[i] = 0;
+    __syncthreads();
+    int *abortw = prog + n, *mready = prog + n + 1 + pair;
+    double *mbox = mbase + (size_t)pair * RING * SB2ST_MBOX;
+
+    int offD[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        offD[r] = (i >= j) ? j * SBW + (i - j) : i * SBW + (j - i);
+    }
+    const int offC = j * SBW + SB + 4 * g - j;                      // B[4 g + r][j] at offC + r (layout C)
+    const int offR = 4 * g * SBW + SB + j - 4 * g;                  // B[j][4 g + r] at offR + r (SBW - 1) (layout R)
+    const int off0 = SB + j;                                        // B[row = lane & 15][0]
+    const bool g0 = g == 0, j0 = j == 0;
+
+    auto wait_ge = [&](const int *word, int need) -> bool {
+        for (unsigned spins = 0;; ++spins) {
+            const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (p >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 1023u) == 1023u) {
+                const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (ab != 0 || spins > (1u << 24)) {
+                    __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return false;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    };
+
+    bool alive = true;
+    int k = 0;                                                      // steps of this pair so far; step k belongs to wave k & 1
+    SB2ST_T(tk0);
+    for (int s = pair; s < n - 2 && alive; s += NP) {
+        const int nst = (n - s - 3) / SB + 1;
+        double *base = band + (size_t)(s + 1) * SBW;
+        double *lg = vlog + (size_t)s * tmax * 16 + j;
+        for (int t = 0; t < nst; ++t, base += SB * SBW, lg += 16, ++k) {
+            if ((k & 1) != me) continue;
+            SB2ST_T(ts0);
+            if (s > 0 && !wait_ge(prog + s - 1, t + 2)) { alive = false; break; }
+            double d[4], bc[4], br[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[r] = base[offD[r]];
+                bc[r] = base[offC + r];
+                br[r] = base[offR + r * (SBW - 1)];
+            }
+            const double b0 = base[off0];
+            double vj, vr[4], tau;
+            if (t == 0) {                                           // the reflector that clears column s below the sub-diagonal
+                double *col = band + (size_t)s * SBW + 1;
+                const double xj = col[j];
+                double xr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r] = col[4 * g + r];
+                const double alpha = lane0_f64(xj);
+                const double x0 = g0 ? 0.0 : xr[0];
+                const double sigma = rows_sum(x0 * x0 + xr[1] * xr[1] + xr[2] * xr[2] + xr[3] * xr[3]);
+                double beta, scale;
+                house_scalars(alpha, sigma, tau, beta, scale);
+                vj = j0 ? 1.0 : xj * scale;
+                vr[0] = g0 ? 1.0 : xr[0] * scale;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) vr[r] = xr[r] * scale;
+                if (g0) col[j] = j0 ? beta : 0.0;
+            } else {                                                // from the partner's step t - 1
+                if (!wait_ge(mready, k)) { alive = false; break; }
+                const double *mb = mbox + (size_t)(k % RING) * SB2ST_MBOX;
+                vj = mb[j];
+                tau = mb[16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vr[r] = mb[4 * g + r];
+            }
+            SB2ST_T(ts1);
+            SB2ST_ADD(0, ts1 - ts0);
+            if (g0) *lg = j0 ? tau : vj;
+            // ---- chain part: z = B v, x = first column of B H, the next reflector -> mailbox
+            const double tz = tau * rows_sum(br[0] * vr[0] + br[1] * vr[1] + br[2] * vr[2] + br[3] * vr[3]);
+            const double x = b0 - tz;
+            const double u = rows_sum(d[0] * vr[0] + d[1] * vr[1] + d[2] * vr[2] + d[3] * vr[3]);
+            if (g0) {
+                scr[16 + j] = tz;
+                scr[32 + j] = x;
+            }
+            const double alpha2 = lane0_f64(x);
+            const double sigma2 = row16_sum(j0 ? 0.0 : x * x);
+            double tau2, beta2, scale2;
+            house_scalars(alpha2, sigma2, tau2, beta2, scale2);
+            const double v2j = j0 ? 1.0 : x * scale2;
+            if (t + 1 < nst) {
+                double *mb = mbox + (size_t)((k + 1) % RING) * SB2ST_MBOX;
+                if (g0) mb[j] = v2j;
+                if (lane == 0) mb[16] = tau2;
+                __hip_atomic_store(mready, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            SB2ST_T(ts2);
+            SB2ST_ADD(5, ts2 - ts1);
+            // ---- update part
+            const double gamma = row16_sum(u * vj);
+            const double w = tau * (u - (0.5 * tau * gamma) * vj);
+            if (g0) scr[j] = w;
+            double wr[4], zr[4], xr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wr[r] = scr[4 * g + r];
+                zr[r] = scr[16 + 4 * g + r];
+                xr[r] = scr[32 + 4 * g + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[offD[r]] = d[r] - __dadd_rn(__dmul_rn(vr[r], w), __dmul_rn(wr[r], vj));   // (no fma: symmetry)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bc[r] -= zr[r] * vj;
+            double v2r[4];
+            v2r[0] = g0 ? 1.0 : xr[0] * scale2;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) v2r[r] = xr[r] * scale2;
+            const double tg = tau2 * rows_sum(v2r[0] * bc[0] + v2r[1] * bc[1] + v2r[2] * bc[2] + v2r[3] * bc[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bc[r] -= v2r[r] * tg;
+            if (j0) {
+                bc[0] = g0 ? beta2 : 0.0;
+                bc[1] = bc[2] = bc[3] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[offC + r] = bc[r];
+            SB2ST_T(ts3);
+            if (t > 0 && !wait_ge(prog + s, t)) { alive = false; break; }              // the partner's step t - 1 is complete
+            __hip_atomic_store(prog + s, (t + 1 < nst) ? t + 1 : SB2ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            SB2ST_T(ts4);
+            SB2ST_ADD(1, ts3 - ts2);
+            SB2ST_ADD(3, ts4 - ts3);
+            SB2ST_ADD(2, 1ULL);
+        }
+    }
+    SB2ST_T(tk1);
+    SB2ST_ADD(4, tk1 - tk0);
+    __syncthreads();
+    if (tid == 0 && *abortw != 0) *err = 2;
+    for (int i = tid; i < n; i += NP * 128) {
         D[i] = band[(size_t)i * SBW];
         if (i < n - 1) E[i] = band[(size_t)i * SBW + 1];
     }

@@ -31,6 +31,6 @@ for rep in range(3):
 lib.jcdf_sb2st_profile(out, 0)
 a = np.array(list(out), dtype=np.float64).reshape(16, 8)
 print("n = %d; s_memtime ticks per wave (100 MHz constant clock? compare 'kernel' with the rocprof duration)" % n)
-print("wave   waiting    in steps   steps   per step   prologues    kernel")
+print("wave   waiting    in steps   steps   per step   prologues    kernel   ring wait   (two-wave kernel: even waves = chain, odd = update)")
 for w in range(16):
-    print("%4d %10.0f %10.0f %7.0f %9.1f %10.0f %10.0f" % (w, a[w, 0], a[w, 1], a[w, 2], a[w, 1] / max(a[w, 2], 1), a[w, 3], a[w, 4]))
+    print("%4d %10.0f %10.0f %7.0f %9.1f %10.0f %10.0f %10.0f" % (w, a[w, 0], a[w, 1], a[w, 2], a[w, 1] / max(a[w, 2], 1), a[w, 3], a[w, 4], a[w, 5]))
