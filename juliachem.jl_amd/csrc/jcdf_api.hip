@@ -1342,8 +1342,8 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
 // ---- two-stage tridiagonalisation (jcdf_sbr.hpp): dense -> band (16) -> tridiagonal, Q accumulated forwards -------------
 namespace {
 struct Sytrd2Layout {
-    int64_t n, tmax, ntile;
-    size_t off_v, off_y, off_w, off_t, off_m1, off_ab, off_log, total;
+    int64_t n, tmax, ntile, npanel;
+    size_t off_v, off_y, off_t, off_m1, off_ab, off_log, total;
 };
 Sytrd2Layout sytrd2_layout(int64_t n)
 {
@@ -1353,15 +1353,35 @@ Sytrd2Layout sytrd2_layout(int64_t n)
     L.ntile = (n + 15) / 16;
     size_t o = 64;
     auto take = [&](size_t doubles) { const size_t at = o; o += (doubles * 8 + 63) / 64 * 64; return at; };
-    L.off_v = take((size_t)n * 16);
+    L.npanel = std::max<int64_t>(1, n / SB);
+    L.off_v = take((size_t)L.npanel * n * 16);                   // V and T of every panel (the Q update trails on a side stream)
     L.off_y = take((size_t)n * 16);
-    L.off_w = take((size_t)n * 16);
-    L.off_t = take(256);
+    L.off_t = take((size_t)L.npanel * 256);
     L.off_m1 = take((size_t)L.ntile * 256);
     L.off_ab = take((size_t)n * SBW);
     L.off_log = take((size_t)n * L.tmax * 16);
     L.total = o;
     return L;
+}
+struct Sytrd2Side {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> events;
+};
+std::mutex g_sytrd2_mutex;
+std::map<int, Sytrd2Side> g_sytrd2_side;                          // per device
+Sytrd2Side *sytrd2_side(size_t nevents)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_sytrd2_mutex);
+    Sytrd2Side &sd = g_sytrd2_side[dev];
+    if (!sd.stream && hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    while (sd.events.size() < nevents) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        sd.events.push_back(e);
+    }
+    return &sd;
 }
 constexpr int SB2ST_WAVES = 16;
 size_t sb2st_lds(int64_t n) { return (size_t)(n + 16) * SBW * 8 + SB2ST_WAVES * 48 * 8 + (size_t)(n + 2) * 4; }
@@ -1405,18 +1425,61 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     if (hipMemsetAsync(w, 0, 64, st) != hipSuccess) return JCDF_ERR_HIP;
     const int ni = (int)n;
     hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_Q, (int)ldq, ni);
+    // Q <- Q (I - V T V^T), panel after panel, needs only the stored V_k, T_k: all of it runs on a side stream of the device
+    // BESIDE THE CHASE (one CU, ~1 ms) instead of inside stage 1 (per-panel events cost ~7 us each on the main stream:
+    // measured); JCDF_SBR_Q_INLINE=1: right behind each panel's QR on `stream` itself
+    static const bool q_inline = getenv("JCDF_SBR_Q_INLINE") && atoi(getenv("JCDF_SBR_Q_INLINE")) != 0;
+    Sytrd2Side *sd = q_inline ? nullptr : sytrd2_side(2);
+    if (!q_inline && !sd) return JCDF_ERR_HIP;
+    // per panel k: [QR of panel k] -> Y = A22 V -> [A22 update (and, JCDF_SBR_FUSE=1, the QR of panel k+1 in the same launch)]
+    auto Vb = [&](int k) { return V + (size_t)k * n * 16; };
+    auto Tb = [&](int k) { return T + (size_t)k * 256; };
+    bool hip_ok = true;
+    auto q_update = [&](int k, hipStream_t qs) {
+        hipLaunchKernelGGL(k_sbr_qupdate, dim3((unsigned)((ni + 15) / 16)), dim3(256), 0, qs, ni, (k + 1) * SB, Vb(k), Tb(k), d_Q, (int)ldq);
+    };
+    auto after_panel = [&](int k) {                                 // V_k, T_k are final on `st` here
+        if (!sd) q_update(k, st);
+    };
+    auto launch_panel = [&](int k) {
+        const int m = ni - (k + 1) * SB, nrow = (m + 255) / 256;
+        if (nrow <= 1) hipLaunchKernelGGL(k_sbr_panel<1>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
+        else if (nrow <= 2) hipLaunchKernelGGL(k_sbr_panel<2>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
+        else if (nrow <= 3) hipLaunchKernelGGL(k_sbr_panel<3>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
+        else hipLaunchKernelGGL(k_sbr_panel<5>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
+        after_panel(k);
+    };
+    // JCDF_SBR_FUSE=1: the QR of panel k+1 as one more block of panel k's update launch (2 launches per panel instead of 3);
+    // measured no faster (n = 510: 38-42 us per fused launch against 22 + 14.5 us), so the plain sequence is the default
+    static const bool fuse = getenv("JCDF_SBR_FUSE") && atoi(getenv("JCDF_SBR_FUSE")) != 0;
+    if (ni - SB >= 2) launch_panel(0);
     for (int k = 0; ni - (k + 1) * SB >= 2; ++k) {
-        const int r0 = (k + 1) * SB, m = ni - r0, nrow = (m + 255) / 256;
-        if (nrow <= 1) hipLaunchKernelGGL(k_sbr_panel<1>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
-        else if (nrow <= 2) hipLaunchKernelGGL(k_sbr_panel<2>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
-        else if (nrow <= 3) hipLaunchKernelGGL(k_sbr_panel<3>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
-        else hipLaunchKernelGGL(k_sbr_panel<5>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, V, T);
+        const int r0 = (k + 1) * SB, m = ni - r0;
         const int ntile = (m + 15) / 16, nt1 = (m + 31) / 32;
-        hipLaunchKernelGGL(k_sbr_y, dim3((unsigned)ntile), dim3(SBR_YW * 64), 0, st, d_A, (int)lda, ni, r0, V, Y, M1p);
-        hipLaunchKernelGGL(k_sbr_update, dim3((unsigned)(nt1 * nt1 + (ni + 15) / 16)), dim3(256), 0, st, d_A, (int)lda, ni, r0, V, Y,
-                           T, M1p, ntile, d_Q, (int)ldq, nt1);
+        hipLaunchKernelGGL(k_sbr_y, dim3((unsigned)ntile), dim3(SBR_YW * 64), 0, st, d_A, (int)lda, ni, r0, Vb(k), Y, M1p);
+        const bool next = ni - (k + 2) * SB >= 2;
+        const int nrown = (next && fuse) ? (m - 16 + 255) / 256 : 0;
+        const int ntb = nrown > 0 ? std::min(nt1 * nt1, 160) : nt1 * nt1;   // with a panel block: every block resident at once, that block first
+        const unsigned nblk = (unsigned)(ntb + (nrown > 0 ? 1 : 0));
+#define JCDF_UPD(NR) hipLaunchKernelGGL(k_sbr_update<NR>, dim3(nblk), dim3(256), 0, st, d_A, (int)lda, ni, r0, Vb(k), Y, Tb(k), M1p, ntile, \
+                                        nt1, ntb, Vb(k + 1), Tb(k + 1))
+        if (nrown == 0) JCDF_UPD(0);
+        else if (nrown == 1) JCDF_UPD(1);
+        else if (nrown == 2) JCDF_UPD(2);
+        else if (nrown == 3) JCDF_UPD(3);
+        else JCDF_UPD(5);
+#undef JCDF_UPD
+        if (next) {
+            if (fuse) after_panel(k + 1);
+            else launch_panel(k + 1);
+        }
     }
     hipLaunchKernelGGL(k_sbr_extract, dim3((unsigned)((n * SBW + 255) / 256)), dim3(256), 0, st, d_A, (int)lda, ni, AB);
+    if (sd) {
+        hip_ok = hip_ok && hipEventRecord(sd->events[0], st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->events[0], 0) == hipSuccess;
+        for (int k = 0; ni - (k + 1) * SB >= 2; ++k) q_update(k, sd->stream);
+        hip_ok = hip_ok && hipEventRecord(sd->events[1], sd->stream) == hipSuccess;
+    }
     // two waves per sweep (chain + update) where the ring fits beside the band; JCDF_SB2ST_ONE_WAVE=1: the one-wave kernel
     static const int variant = getenv("JCDF_SB2ST_VARIANT") ? atoi(getenv("JCDF_SB2ST_VARIANT")) : 1;   // 1: one wave per sweep (fastest measured), 2: chain + update waves, 3: ping-pong
     const bool one_wave = variant == 1;
@@ -1448,7 +1511,8 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
         else JCDF_CHASE1(16);
 #undef JCDF_CHASE1
     }
-    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+    if (sd) hip_ok = hip_ok && hipStreamWaitEvent(st, sd->events[1], 0) == hipSuccess;   // d_Q is complete for whatever follows on `stream`
+    return (hip_ok && hipGetLastError() == hipSuccess) ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 #ifdef JCDF_SB2ST_PROFILE

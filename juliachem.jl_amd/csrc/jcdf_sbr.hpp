@@ -110,23 +110,23 @@ __device__ __forceinline__ void house_scalars(double alpha, double sigma, double
 // V[:, c']^T v of the T recurrence (c' < c) at once, because v = (1, x * scale).
 // Out: Vbuf[m][16] (unit lower trapezoidal), Tbuf[16][16] (upper triangular, Q = I - V T V^T), and R / zeros into
 // A[j0+c][r0+i] (the upper-triangle image of the panel; the band is read from there by k_sbr_extract).
+struct SbrPanelLds {
+    double part[16][64];                                  // [value][wave * 16 + lane & 15]: partial sums over 4 lanes each
+    double tot[16];
+    double prow[2][16];
+    double sS[16][17];                                    // S[c'][c] = V[:, c']^T v_c (c' < c) and tau_c on the diagonal, for T
+};
+
+// QR of the panel held in registers (p[q][c] = P[tid + 256 q][c], rows >= m are 0) by the 256 threads of the workgroup
 template <int NROW>
-__global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int lda, int n, int k, double *__restrict__ Vbuf,
-                                                   double *__restrict__ Tbuf)
+__device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLds &L, double *__restrict__ A, int lda, int j0, int r0,
+                                               int m, double *__restrict__ Vbuf, double *__restrict__ Tbuf)
 {
-    __shared__ double part[16][64];                     // [value][wave * 16 + lane & 15]: partial sums over 4 lanes each
-    __shared__ double tot[16];
-    __shared__ double prow[2][16];
-    __shared__ double sS[16][17];                         // S[c'][c] = V[:, c']^T v_c (c' < c) and tau_c on the diagonal, for T
+    double (&part)[16][64] = L.part;
+    double (&tot)[16] = L.tot;
+    double (&prow)[2][16] = L.prow;
+    double (&sS)[16][17] = L.sS;
     const int tid = threadIdx.x;
-    const int j0 = k * SB, r0 = j0 + SB, m = n - r0;
-    double p[NROW][16];
-#pragma unroll
-    for (int q = 0; q < NROW; ++q) {
-        const int i = tid + 256 * q;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) p[q][c] = (i < m) ? A[(size_t)(j0 + c) * lda + r0 + i] : 0.0;
-    }
     const int tr = tid & 15;
     const int gq = (tid >> 4) & 3;                        // 16-lane row of the wave
     const int myval = 2 * (gq & 1) + (gq >> 1);           // after the two pair sums this row holds values 4 q + myval
@@ -217,6 +217,23 @@ __global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int l
     }
 }
 
+template <int NROW>
+__global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int lda, int n, int k, double *__restrict__ Vbuf,
+                                                   double *__restrict__ Tbuf)
+{
+    __shared__ SbrPanelLds L;
+    const int tid = threadIdx.x;
+    const int j0 = k * SB, r0 = j0 + SB, m = n - r0;
+    double p[NROW][16];
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+        const int i = tid + 256 * q;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) p[q][c] = (i < m) ? A[(size_t)(j0 + c) * lda + r0 + i] : 0.0;
+    }
+    sbr_panel_core<NROW>(p, L, A, lda, j0, r0, m, Vbuf, Tbuf);
+}
+
 // acc += sum over the k steps [ks0, ks1) of A-operand x B-operand, eight k steps of loads in flight at a time (the
 // operands come straight from L2: one load round trip per MFMA would otherwise bound these loops)
 template <class FA, class FB>
@@ -284,27 +301,36 @@ __global__ __launch_bounds__(SBR_YW * 64) void k_sbr_y(const double *__restrict_
 // blocks [0, nt2): A22 <- A22 - V W^T - W V^T on 32 x 32 tiles, W = Y T - V N2, N2 = 1/2 (T^T M1) T (M1 = sum of the
 // tile parts of k_sbr_y, fixed order): every workgroup forms N2 and the 2 x 32 rows of W it needs itself (one more
 // launch per panel would cost more), then 4 waves x one 16 x 16 MFMA tile with K = 2 x 16;
-// blocks [nt2, nt2 + ceil(n/16)): 16 rows of Q:  Q[I, r0:] <- Q[I, r0:] - ((Q[I, r0:] V) T) V^T.
+// NROWN > 0 (optional, JCDF_SBR_FUSE): one more block runs the QR of the NEXT panel (columns r0 .. r0+15, rows r0+16 ..) inside this launch — the
+// one-workgroup QR is the longest item of a panel step and needs only its own 16 columns updated, which it does itself:
+//   P[i][c] = A[r0+c][r0+16+i] - sum_q V[16+i][q] G1[q][c] + Y[16+i][q] G2[q][c],
+//   G1 = W_top^T - N2 V_top^T,  G2 = T V_top^T  (V_top, W_top: the first 16 rows)
+// while the tile blocks leave the two strips (rows < 16) != (cols < 16) of A22 alone (the upper one receives R, the lower one
+// is dead).  The next panel's V and T go to the other buffer pair.
+template <int NROWN>
 __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int lda, int n, int r0, const double *__restrict__ Vbuf,
                                                     const double *__restrict__ Ybuf, const double *__restrict__ Tbuf,
-                                                    const double *__restrict__ M1p, int ntile, double *__restrict__ Q, int ldq, int nt1)
+                                                    const double *__restrict__ M1p, int ntile, int nt1, int ntb,
+                                                    double *__restrict__ Vnext, double *__restrict__ Tnext)
 {
+    // block roles: [panel block (NROWN > 0)] [ntb tile blocks, each takes the tiles bid, bid + ntb, ...]
     const int m = n - r0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int nt2 = nt1 * nt1;
     __shared__ double sT[16][17], sM[16][17], sN[16][17];
     __shared__ double sW[4][16][17];
-    __shared__ double red[4][4][64];
-    if ((int)blockIdx.x < nt2) {
+    const bool is_panel = NROWN > 0 && blockIdx.x == 0;
+    const int bid = (int)blockIdx.x - (NROWN > 0 ? 1 : 0);
+    if (bid < ntb || is_panel) {
         {
             const int r = tid >> 4, c = tid & 15;
             double m1 = 0.0;
-            for (int t = 0; t < ntile; t += 8) {                                // fixed order; eight loads in flight
-                double e[8];
+            for (int t = 0; t < ntile; t += 40) {                               // fixed order; all loads of a pass in flight (one L2 round trip)
+                double e[40];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) e[u] = (t + u < ntile) ? M1p[(size_t)(t + u) * 256 + tid] : 0.0;
+                for (int u = 0; u < 40; ++u) e[u] = (t + u < ntile) ? M1p[(size_t)(t + u) * 256 + tid] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) m1 += e[u];
+                for (int u = 0; u < 40; ++u) m1 += e[u];
             }
             sM[r][c] = m1;
             sT[r][c] = Tbuf[tid];
@@ -320,51 +346,119 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
             sM[r][c] = -0.5 * n2;                                               // -N2
             __syncthreads();
         }
-        const int Ib = (blockIdx.x / nt1) * 32, Jb = (blockIdx.x % nt1) * 32;
-        // wave w forms the 16 rows of W starting at R_w = (Ib, Ib+16, Jb, Jb+16)[w]: [Y | V] (16 x 32) x [T ; -N2] (32 x 16)
-        {
-            const int R = (wave < 2 ? Ib : Jb) + (wave & 1) * 16;
-            const bool ok = R + lr < m;
-            double4_t wacc = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (NROWN > 0) {
+            if (is_panel) {
+                __shared__ SbrPanelLds L;
+                __shared__ __attribute__((aligned(16))) double sG1[16][16], sG2[16][16];
+                const int r = tid >> 4, c = tid & 15;
+                // W_top[r][c] and V_top[r][c] (rows r < 16 of A22; m >= 18 here)
+                double wt = 0.0;
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const int kk = 4 * s_ + lk;
-                const double y = ok ? Ybuf[(size_t)(R + lr) * 16 + kk] : 0.0, v = ok ? Vbuf[(size_t)(R + lr) * 16 + kk] : 0.0;
-                wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, sT[kk][lr], wacc, 0, 0, 0);
-                wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, sM[kk][lr], wacc, 0, 0, 0);
+                for (int e = 0; e < 16; ++e) wt += Ybuf[r * 16 + e] * sT[e][c] + Vbuf[r * 16 + e] * sM[e][c];
+                sW[0][r][c] = wt;
+                sW[1][r][c] = Vbuf[r * 16 + c];
+                __syncthreads();
+                // G1[q][c] = W_top[c][q] + sum_e (-N2)[q][e] V_top[c][e],  G2[q][c] = sum_e T[q][e] V_top[c][e]   (q = r here)
+                double g1 = sW[0][c][r], g2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    g1 += sM[r][e] * sW[1][c][e];
+                    g2 += sT[r][e] * sW[1][c][e];
+                }
+                sG1[r][c] = g1;
+                sG2[r][c] = g2;
+                __syncthreads();
+                const int mp = m - 16;                                          // rows of the next panel
+                double p[NROWN][16];
+                double vr_[NROWN][16], yr_[NROWN][16];
+#pragma unroll
+                for (int q = 0; q < NROWN; ++q) {
+                    const int i = tid + 256 * q;
+                    const bool in = i < mp;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        vr_[q][e] = in ? Vbuf[(size_t)(16 + i) * 16 + e] : 0.0;
+                        yr_[q][e] = in ? Ybuf[(size_t)(16 + i) * 16 + e] : 0.0;
+                        p[q][e] = in ? A[(size_t)(r0 + e) * lda + r0 + 16 + i] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    double g1r[16], g2r[16];
+#pragma unroll
+                    for (int cc = 0; cc < 16; cc += 2) {
+                        const double2_t a = *reinterpret_cast<const double2_t *>(&sG1[e][cc]);
+                        const double2_t b = *reinterpret_cast<const double2_t *>(&sG2[e][cc]);
+                        g1r[cc] = a[0]; g1r[cc + 1] = a[1];
+                        g2r[cc] = b[0]; g2r[cc + 1] = b[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NROWN; ++q)
+#pragma unroll
+                        for (int cc = 0; cc < 16; ++cc) p[q][cc] -= vr_[q][e] * g1r[cc] + yr_[q][e] * g2r[cc];
+                }
+                sbr_panel_core<NROWN>(p, L, A, lda, r0, r0 + 16, mp, Vnext, Tnext);
+                return;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sW[wave][lk + 4 * r][lr] = wacc[r];
         }
-        __syncthreads();
-        const int wi = wave >> 1, wj = wave & 1;                                // tile (I, J) = (Ib + 16 wi, Jb + 16 wj)
-        const int I = Ib + wi * 16, J = Jb + wj * 16;
-        if (I >= m || J >= m) return;
-        double4_t acc;
+        for (int tile = bid; tile < nt2; tile += ntb) {
+            const int Ib = (tile / nt1) * 32, Jb = (tile % nt1) * 32;
+            // wave w forms the 16 rows of W starting at R_w = (Ib, Ib+16, Jb, Jb+16)[w]: [Y | V] (16 x 32) x [T ; -N2] (32 x 16)
+            {
+                const int R = (wave < 2 ? Ib : Jb) + (wave & 1) * 16;
+                const bool ok = R + lr < m;
+                double4_t wacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = I + lk + 4 * r, col = J + lr;
-            acc[r] = (row < m && col < m) ? A[(size_t)(r0 + row) * lda + r0 + col] : 0.0;
-        }
-        const bool iok = I + lr < m, jok = J + lr < m;
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int kk = 4 * s_ + lk;
+                    const double y = ok ? Ybuf[(size_t)(R + lr) * 16 + kk] : 0.0, v = ok ? Vbuf[(size_t)(R + lr) * 16 + kk] : 0.0;
+                    wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, sT[kk][lr], wacc, 0, 0, 0);
+                    wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, sM[kk][lr], wacc, 0, 0, 0);
+                }
+                __syncthreads();                                                // the previous tile's readers of sW are done
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            const int kk = 4 * s_ + lk;
-            const double vi = iok ? Vbuf[(size_t)(I + lr) * 16 + kk] : 0.0, wi_ = sW[wi][lr][kk];
-            const double vj = jok ? Vbuf[(size_t)(J + lr) * 16 + kk] : 0.0, wj_ = sW[2 + wj][lr][kk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj_, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi_, vj, acc, 0, 0, 0);
-        }
+                for (int r = 0; r < 4; ++r) sW[wave][lk + 4 * r][lr] = wacc[r];
+            }
+            __syncthreads();
+            const int wi = wave >> 1, wj = wave & 1;                            // tile (I, J) = (Ib + 16 wi, Jb + 16 wj)
+            const int I = Ib + wi * 16, J = Jb + wj * 16;
+            if (I < m && J < m) {
+                double4_t acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = I + lk + 4 * r, col = J + lr;
-            if (row < m && col < m) A[(size_t)(r0 + row) * lda + r0 + col] = acc[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = I + lk + 4 * r, col = J + lr;
+                    acc[r] = (row < m && col < m) ? A[(size_t)(r0 + row) * lda + r0 + col] : 0.0;
+                }
+                const bool iok = I + lr < m, jok = J + lr < m;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int kk = 4 * s_ + lk;
+                    const double vi = iok ? Vbuf[(size_t)(I + lr) * 16 + kk] : 0.0, wi_ = sW[wi][lr][kk];
+                    const double vj = jok ? Vbuf[(size_t)(J + lr) * 16 + kk] : 0.0, wj_ = sW[2 + wj][lr][kk];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj_, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi_, vj, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = I + lk + 4 * r, col = J + lr;
+                    if (row < m && col < m && (NROWN == 0 || (row < 16) == (col < 16))) A[(size_t)(r0 + row) * lda + r0 + col] = acc[r];
+                }
+            }
         }
         return;
     }
-    // ---- rows of Q
-    double (*zt)[17] = sN;
-    const int I = ((int)blockIdx.x - nt2) * 16;
+}
+
+// 16 rows of Q per block:  Q[I, r0:] <- Q[I, r0:] - ((Q[I, r0:] V) T) V^T.  Off the critical path of stage 1 (nothing there
+// reads Q): launched on a side stream behind the panel's QR, it runs beside the next panels' kernels.
+__global__ __launch_bounds__(256) void k_sbr_qupdate(int n, int r0, const double *__restrict__ Vbuf, const double *__restrict__ Tbuf,
+                                                     double *__restrict__ Q, int ldq)
+{
+    const int m = n - r0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    __shared__ double zt[16][17];
+    __shared__ double red[4][4][64];
+    const int I = (int)blockIdx.x * 16;
     const bool rowok = I + lr < n;
     {
         // Z = Q[I, r0:] V: A operand [row = i][k = j] = Q[I+i][r0+j], B operand [k = j][col = c] = V[j][c]
