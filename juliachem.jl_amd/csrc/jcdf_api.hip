@@ -1442,11 +1442,17 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
         if (!sd) q_update(k, st);
     };
     auto launch_panel = [&](int k) {
-        const int m = ni - (k + 1) * SB, nrow = (m + 255) / 256;
-        if (nrow <= 1) hipLaunchKernelGGL(k_sbr_panel<1>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
-        else if (nrow <= 2) hipLaunchKernelGGL(k_sbr_panel<2>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
-        else if (nrow <= 3) hipLaunchKernelGGL(k_sbr_panel<3>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
-        else hipLaunchKernelGGL(k_sbr_panel<5>, dim3(1), dim3(256), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k));
+        const int m = ni - (k + 1) * SB;
+        // JCDF_SBR_PANEL_512=1: 512 threads above 256 rows (two waves per SIMD; measured slower: 256 registers per thread spill)
+        static const bool wide = getenv("JCDF_SBR_PANEL_512") && atoi(getenv("JCDF_SBR_PANEL_512")) != 0;
+#define JCDF_PANEL(NR, NT_) hipLaunchKernelGGL((k_sbr_panel<NR, NT_>), dim3(1), dim3(NT_), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k))
+        if (m <= 256) JCDF_PANEL(1, 256);
+        else if (wide && m <= 512) JCDF_PANEL(1, 512);
+        else if (wide && m <= 1024) JCDF_PANEL(2, 512);
+        else if (m <= 512) JCDF_PANEL(2, 256);
+        else if (m <= 768) JCDF_PANEL(3, 256);
+        else JCDF_PANEL(5, 256);
+#undef JCDF_PANEL
         after_panel(k);
     };
     // JCDF_SBR_FUSE=1: the QR of panel k+1 as one more block of panel k's update launch (2 launches per panel instead of 3);

@@ -110,19 +110,21 @@ __device__ __forceinline__ void house_scalars(double alpha, double sigma, double
 // V[:, c']^T v of the T recurrence (c' < c) at once, because v = (1, x * scale).
 // Out: Vbuf[m][16] (unit lower trapezoidal), Tbuf[16][16] (upper triangular, Q = I - V T V^T), and R / zeros into
 // A[j0+c][r0+i] (the upper-triangle image of the panel; the band is read from there by k_sbr_extract).
+template <int NT>
 struct SbrPanelLds {
-    double part[16][64];                                  // [value][wave * 16 + lane & 15]: partial sums over 4 lanes each
+    double part[16][NT / 4];                              // [value][wave * 16 + lane & 15]: partial sums over 4 lanes each
     double tot[16];
     double prow[2][16];
     double sS[16][17];                                    // S[c'][c] = V[:, c']^T v_c (c' < c) and tau_c on the diagonal, for T
 };
 
-// QR of the panel held in registers (p[q][c] = P[tid + 256 q][c], rows >= m are 0) by the 256 threads of the workgroup
-template <int NROW>
-__device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLds &L, double *__restrict__ A, int lda, int j0, int r0,
+// QR of the panel held in registers (p[q][c] = P[tid + NT q][c], rows >= m are 0) by the NT threads of the workgroup
+// (NT = 512: two waves per SIMD — a lone wave issues one instruction per 4 cycles, two share the SIMD at 2)
+template <int NROW, int NT>
+__device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLds<NT> &L, double *__restrict__ A, int lda, int j0, int r0,
                                                int m, double *__restrict__ Vbuf, double *__restrict__ Tbuf)
 {
-    double (&part)[16][64] = L.part;
+    double (&part)[16][NT / 4] = L.part;
     double (&tot)[16] = L.tot;
     double (&prow)[2][16] = L.prow;
     double (&sS)[16][17] = L.sS;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
         for (int cc = 0; cc < 16; ++cc) h[cc] = 0.0;
 #pragma unroll
         for (int q = 0; q < NROW; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NT * q;
             const double x = (i > c) ? p[q][c] : 0.0;
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) h[cc] += x * p[q][cc];
@@ -150,7 +152,7 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] = pair_sum32(h[2 * e], h[2 * e + 1]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pdst[(size_t)(4 * e) * 64] = pair_sum16(s1[2 * e], s1[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) pdst[(size_t)(4 * e) * (NT / 4)] = pair_sum16(s1[2 * e], s1[2 * e + 1]);
         if (tid == c) {
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) prow[c & 1][cc] = p[0][cc];
@@ -158,9 +160,13 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
         __syncthreads();
         {
             const int cq = tid >> 4, ch = tid & 15;
-            double sv = (part[cq][ch] + part[cq][ch + 16]) + (part[cq][ch + 32] + part[cq][ch + 48]);
+            double sv = 0.0;
+            if (NT == 256 || cq < 16) {
+#pragma unroll
+                for (int e = 0; e < NT / 64; ++e) sv += part[cq & 15][ch + 16 * e];
+            }
             sv = row16_sum(sv);
-            if (ch == 0) tot[cq] = sv;
+            if (ch == 0 && (NT == 256 || cq < 16)) tot[cq & 15] = sv;
         }
         __syncthreads();
         double hs[16], pr[16];
@@ -176,7 +182,7 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
         // ---- P[:, c'] -= v w[c'], w[c'] = tau (P[c][c'] + scale h[c'])  (c' > c);  column c <- (beta, v)
 #pragma unroll
         for (int q = 0; q < NROW; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NT * q;
             const double vi = (i > c) ? p[q][c] * scale : ((i == c) ? 1.0 : 0.0);
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc)
@@ -202,7 +208,7 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
     // ---- out
 #pragma unroll
     for (int q = 0; q < NROW; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + NT * q;
         if (i < m) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -217,21 +223,21 @@ __device__ __forceinline__ void sbr_panel_core(double (&p)[NROW][16], SbrPanelLd
     }
 }
 
-template <int NROW>
-__global__ __launch_bounds__(256) void k_sbr_panel(double *__restrict__ A, int lda, int n, int k, double *__restrict__ Vbuf,
-                                                   double *__restrict__ Tbuf)
+template <int NROW, int NT>
+__global__ __launch_bounds__(NT) void k_sbr_panel(double *__restrict__ A, int lda, int n, int k, double *__restrict__ Vbuf,
+                                                  double *__restrict__ Tbuf)
 {
-    __shared__ SbrPanelLds L;
+    __shared__ SbrPanelLds<NT> L;
     const int tid = threadIdx.x;
     const int j0 = k * SB, r0 = j0 + SB, m = n - r0;
     double p[NROW][16];
 #pragma unroll
     for (int q = 0; q < NROW; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + NT * q;
 #pragma unroll
         for (int c = 0; c < 16; ++c) p[q][c] = (i < m) ? A[(size_t)(j0 + c) * lda + r0 + i] : 0.0;
     }
-    sbr_panel_core<NROW>(p, L, A, lda, j0, r0, m, Vbuf, Tbuf);
+    sbr_panel_core<NROW, NT>(p, L, A, lda, j0, r0, m, Vbuf, Tbuf);
 }
 
 // acc += sum over the k steps [ks0, ks1) of A-operand x B-operand, eight k steps of loads in flight at a time (the
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
         }
         if constexpr (NROWN > 0) {
             if (is_panel) {
-                __shared__ SbrPanelLds L;
+                __shared__ SbrPanelLds<256> L;
                 __shared__ __attribute__((aligned(16))) double sG1[16][16], sG2[16][16];
                 const int r = tid >> 4, c = tid & 15;
                 // W_top[r][c] and V_top[r][c] (rows r < 16 of A22; m >= 18 here)
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256) void k_sbr_update(double *__restrict__ A, int 
 #pragma unroll
                         for (int cc = 0; cc < 16; ++cc) p[q][cc] -= vr_[q][e] * g1r[cc] + yr_[q][e] * g2r[cc];
                 }
-                sbr_panel_core<NROWN>(p, L, A, lda, r0, r0 + 16, mp, Vnext, Tnext);
+                sbr_panel_core<NROWN, 256>(p, L, A, lda, r0, r0 + 16, mp, Vnext, Tnext);
                 return;
             }
         }
