@@ -697,6 +697,42 @@ def test_rhf_run_reproduces_reference_energies(case, flags, tol):
     assert abs(np.trace(res["Density"] @ res["Overlap"]) - 10.0) < 1e-9            # 10 electrons
 
 
+STO3G = {   # published STO-3G tables (Hehre, Stewart, Pople 1969); the snapshot of the reference holds no STO-3G table or output
+    "H": [{"l": 0, "exps": [3.42525091, 0.62391373, 0.16885540], "coefs": [0.15432897, 0.53532814, 0.44463454]}],
+    "O": [{"l": 0, "exps": [130.7093200, 23.8088610, 6.4436083], "coefs": [0.15432897, 0.53532814, 0.44463454]},
+          {"l": 0, "exps": [5.0331513, 1.1695961, 0.3803890], "coefs": [-0.09996723, 0.39951283, 0.70011547]},
+          {"l": 1, "exps": [5.0331513, 1.1695961, 0.3803890], "coefs": [0.15591627, 0.60768372, 0.39195739]}],
+}
+
+
+def test_config1_standin_water_sto3g():
+    """Stand-in for BASELINE config 1 (H2O / STO-3G, example_inputs/density_fitting/water_rhf.json: the reference's CPU plumbing
+    case, which cannot run here without Julia): the same molecule class and a minimal basis through `rhf.run` (host integrals ->
+    device B -> device SCF), dense and screened, against the CPU oracle on the oracle's own integrals.  The auxiliary basis is the
+    cc-pVDZ-RIFIT table of the golden water log (def2-universal-JKFIT is not in the snapshot).  Parity with the reference itself
+    is UNPINNED for this case: the reference holds no STO-3G output; the energy is only checked against the textbook range."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    from oracle import integrals as gi, scf as oscf
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = g["atoms"]
+    f = {"dele": 1e-8, "rmsd": 1e-8, "niter": 60}
+    res = rhf.run(atoms, g["charges"], STO3G, g["aux_basis"], f)
+    scr = rhf.run(atoms, g["charges"], STO3G, g["aux_basis"], dict(f, df_use_adaptive=False))
+    assert res["Converged?"] and scr["Converged?"]
+    prim = gi.build_shells(atoms, STO3G); aux = gi.build_shells(atoms, g["aux_basis"])
+    assert sum(s.nbas for s in prim) == 7
+    Z = [g["charges"][a["symbol"]] for a in atoms]; R = np.array([a["center"] for a in atoms])
+    S, T, V = gi.one_electron(prim, Z, R)
+    B = orc.calculate_B(gi.two_center(aux), gi.three_center(aux, prim))
+    ref = oscf.rhf_df_scf(T + V, S, gi.nuclear_repulsion(Z, R), 5, lambda C, it: T + V + orc.df_rhf_fock_build_BLAS(B, C[:, :5]),
+                          dele=1e-8, rmsd=1e-8, niter=60)
+    assert ref.converged and abs(res["Energy"] - ref.energy) < 1e-9 and res["Iterations"] == ref.iterations
+    assert abs(scr["Energy"] - res["Energy"]) < 1e-6
+    assert -75.1 < res["Energy"] < -74.7                                    # RHF / STO-3G water: -74.96 Eh near equilibrium
+
+
 def test_rhf_run_water_dimer_screened_equals_dense():
     """A water dimer 7 bohr apart: the Schwarz mask really drops pairs (packed layout, block-sparse W/J); the screened
     energy agrees with the dense one to the screening error, and both with the CPU oracle's dense SCF on the oracle's
