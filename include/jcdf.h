@@ -204,6 +204,11 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* Q of A = Q T Q^T rebuilt from the reflectors jcdf_sytrd_device left in d_A / d_TAU (LAPACK dorgtr's matrix, row-major,
+ * leading dimension ldq), row-parallel; n <= 640.  It needs neither D nor E: the caller runs it on a second stream beside
+ * jcdf_stedc_device, so that the persistent kernel spends its hand-off window on the rank-2 update instead of on Q. */
+int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU,
+                                   double *d_Q, int64_t ldq);
 /* The same reduction in two stages (csrc/jcdf_sbr.hpp): dense -> band of half-width 16 (one Householder QR per panel of
  * 16 columns inside one workgroup + MFMA block-reflector updates) -> tridiagonal (bulge chasing in the LDS of one
  * workgroup) — 3 n/16 kernel boundaries instead of n chip-wide hand-offs.  jcdf_sytrd2_device leaves D, E (device, n and

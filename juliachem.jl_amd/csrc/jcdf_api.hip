@@ -1332,6 +1332,22 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
     return jcdf_sytrd_q_device(stream, n, d_A, lda, d_D, d_E, d_TAU, nullptr, d_work, work_bytes);
 }
 
+int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU, double *d_Q, int64_t ldq)
+{
+    if (n <= 0 || n > 640 || !d_A || lda < n || !d_TAU || !d_Q || ldq < n) return JCDF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n + 7) / 8);
+#define JCDF_REPLAY(NR) hipLaunchKernelGGL(k_sytrd_replay_q<NR>, dim3(grid), dim3(256), 0, st, d_A, (int)lda, (int)n, d_TAU, d_Q, (int)ldq)
+    if (n <= 64) JCDF_REPLAY(1);
+    else if (n <= 128) JCDF_REPLAY(2);
+    else if (n <= 256) JCDF_REPLAY(4);
+    else if (n <= 384) JCDF_REPLAY(6);
+    else if (n <= 512) JCDF_REPLAY(8);
+    else JCDF_REPLAY(10);
+#undef JCDF_REPLAY
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
 int64_t jcdf_sytrd_max_n(int32_t with_q)
 {
     int64_t n = 64;

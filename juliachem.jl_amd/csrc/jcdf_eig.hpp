@@ -653,6 +653,74 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     }
 }
 
+// ---- k_sytrd_replay_q: Q = H_0 H_1 ... H_{n-3} from the stored reflectors (LAPACK dorgtr's result, row-major) -----------------
+// Optional (DeviceEigh: JCDF_EIGH_Q_REPLAY=1): Q is not needed by the tridiagonal solver, so instead of accumulating it inside the
+// persistent kernel it can be rebuilt afterwards, row-parallel, on a side stream beside the divide & conquer: row r of Q
+// is e_r^T H_0 H_1 ..., two rows per wave in registers (lane l holds columns l, l+64, ...), reflector k read from column k of A
+// (contiguous), the next one prefetched while this one is applied.  ~0.1 ms at n = 510 on a side stream beside the divide &
+// conquer (0.4 ms).  A: n x n column-major LAPACK storage (v_k below the sub-diagonal of column k), TAU[n].
+template <int NR>
+__global__ __launch_bounds__(256) void k_sytrd_replay_q(const double *__restrict__ A, int lda, int n, const double *__restrict__ TAU,
+                                                        double *__restrict__ Q, int ldq)
+{
+    __shared__ double stau[640];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < n; i += 256) stau[i] = (i < n - 2) ? TAU[i] : 0.0;
+    __syncthreads();
+    const int row0 = (blockIdx.x * 4 + wave) * 2;
+    if (row0 >= n) return;
+    double q0[NR], q1[NR], v[NR], v1[NR], v2[NR];                   // reflectors k, k+1, k+2 (two L2 latencies ahead)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        q0[r] = (c == row0) ? 1.0 : 0.0;
+        q1[r] = (c == row0 + 1) ? 1.0 : 0.0;
+    }
+    auto fetch = [&](int k, double (&dst)[NR]) {                    // v_k: 1 at k+1, A[k][c] for c >= k+2, 0 elsewhere
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int c = lane + 64 * r;
+            dst[r] = (k < n - 2 && c >= k + 2 && c < n) ? A[(size_t)k * lda + c] : ((c == k + 1 && k < n - 2) ? 1.0 : 0.0);
+        }
+    };
+    // apply H_k from `use` while reflector k+2 lands in `next` (three register sets in rotation: no copy ever waits for a load)
+    auto step = [&](int k, const double (&use)[NR], double (&next)[NR]) {
+        fetch(k + 2, next);
+        const double tau = stau[k < n - 2 ? k : 0];
+        double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r += 2) {
+            d0a += q0[r] * use[r];
+            d1a += q1[r] * use[r];
+            if (r + 1 < NR) {
+                d0b += q0[r + 1] * use[r + 1];
+                d1b += q1[r + 1] * use[r + 1];
+            }
+        }
+        const double d0 = tau * wave_sum(d0a + d0b), d1 = tau * wave_sum(d1a + d1b);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            q0[r] -= d0 * use[r];
+            q1[r] -= d1 * use[r];
+        }
+    };
+    fetch(0, v);
+    fetch(1, v1);
+    for (int k = 0; k < n - 2; k += 3) {                           // reflectors past n-3 are fetched as zero: H = I
+        step(k, v, v2);
+        step(k + 1, v1, v);
+        step(k + 2, v2, v1);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        if (c < n) {
+            Q[(size_t)row0 * ldq + c] = q0[r];
+            if (row0 + 1 < n) Q[(size_t)(row0 + 1) * ldq + c] = q1[r];
+        }
+    }
+}
+
 // ---- k_diis_solve: the Pulay step of the SCF wrapper without a round trip to the host ----------------------------
 // (reference: DIIS in src/rhf/energy/EnergyHelpers.jl:234-258 — B matrix of error-vector dot products bordered by
 // -1, LAPACK.sysv!('U'), "Faulty DIIS" -> history cut to 2; called from SCF.jl:472-501.)

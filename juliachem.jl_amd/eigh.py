@@ -70,6 +70,12 @@ class DeviceEigh:
             if self.two_stage:
                 self.wb2 = int(self.lib.jcdf_sytrd2_workspace_bytes(n))
                 self.work2 = torch.zeros(self.wb2 // 8 + 8, **f64)
+            # JCDF_EIGH_Q_REPLAY=1 (one-stage kernel, n <= 640): Q rebuilt from the stored reflectors on a side stream beside the
+            # divide & conquer instead of inside the persistent kernel — measured equal inside the SCF loop (the kernel's hand-off
+            # window, not the Q update inside it, sets the time of a column), so the in-kernel accumulation stays the default
+            self.q_replay = (self.with_q and self.own_stedc and not self.two_stage and n <= 640
+                             and os.environ.get("JCDF_EIGH_Q_REPLAY") == "1")
+            if self.two_stage or self.q_replay:
                 self.side = torch.cuda.Stream(device=device)
                 self.ev_fork = torch.cuda.Event()
                 self.ev_join = torch.cuda.Event()
@@ -96,6 +102,8 @@ class DeviceEigh:
         p = lambda t: C.c_void_p(t.data_ptr())
         if self.two_stage:
             return self._two_stage(Fp, st, p)
+        if self.q_replay:
+            return self._one_stage_replay(Fp, st, p)
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
                                           p(self.Q) if self.with_q else None, p(self.work), self.wb)
         own_gemm = self.with_q and self.own_stedc
@@ -147,6 +155,28 @@ class DeviceEigh:
         if rc != 0:
             self.ok = False
             self.reason = "library call failed rc=%d (two-stage reduction)" % rc
+            self.fallbacks += 1
+            return torch.linalg.eigh(Fp)
+        self.U_padded = self.Up
+        return self.D, self.Up[:n, :n]
+
+    def _one_stage_replay(self, Fp, st, p):
+        n, npad = self.n, self.npad
+        main = torch.cuda.current_stream(self.device)
+        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU), None, p(self.work), self.wb)
+        if rc == 0:
+            self.ev_fork.record(main)
+            self.side.wait_event(self.ev_fork)
+            rc = self.lib.jcdf_sytrd_replay_q_device(C.c_void_p(self.side.cuda_stream), n, p(self.A), n, p(self.TAU), p(self.Qp), npad)
+            self.ev_join.record(self.side)
+        if rc == 0:
+            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(self.Zt), npad, p(self.dc_work), self.dc_wb)
+        main.wait_event(self.ev_join)
+        if rc == 0:
+            rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), npad, npad, npad, p(self.Qp), npad, p(self.Zt), npad, p(self.Up), npad)
+        if rc != 0:
+            self.ok = False
+            self.reason = "library call failed rc=%d" % rc
             self.fallbacks += 1
             return torch.linalg.eigh(Fp)
         self.U_padded = self.Up
