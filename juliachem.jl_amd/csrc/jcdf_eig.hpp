@@ -248,7 +248,7 @@ constexpr int SYTRD_CB = 8;      // local columns processed together (independen
 // of Q and must not be overrun: from then on it publishes a heartbeat (k) instead, and the others take
 // its heartbeat (k-1) together with y_k (one step old when asked for, so it costs no waiting, and only
 // the last ~gridDim.x steps have such workgroups at all).
-__global__ __launch_bounds__(256) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
+__global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
                                                      u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
 {
