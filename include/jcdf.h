@@ -216,7 +216,8 @@ int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, i
  * d_work; jcdf_sytrd2_apply_q_device (any stream ordered behind the first call; it needs neither D nor E, so it may run
  * beside jcdf_stedc_device) completes d_Q to the Q of A = Q T Q^T.  d_A (symmetric, fully stored) is overwritten.
  * The int at byte offset 8 of d_work is non-zero afterwards if a wait inside the chase gave up (result invalid).
- * n <= jcdf_sytrd2_max_n() (the band must fit the LDS of one CU: 598). */
+ * n <= jcdf_sytrd2_max_n() (the band must fit the LDS of one CU: 590).  The stage-1 factor is accumulated on an internal
+ * per-device side stream beside the chase and joined into `stream` before the call returns: one call at a time per device. */
 int64_t jcdf_sytrd2_max_n(void);
 int64_t jcdf_sytrd2_workspace_bytes(int64_t n);
 int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_Q,
