@@ -224,6 +224,13 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
                            int64_t ldq, void *d_work, int64_t work_bytes);
 int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t ldq, const void *d_work,
                                    int64_t work_bytes);
+/* Experiment helper (tools/gap_test3.py; not on any product path): `workgroups` workgroups of `threads` (64 / 128 / 256)
+ * threads that stay on the device for `microseconds` — mode 0: sleeping waves only, 1: a dependent fp64 FMA chain per wave,
+ * 2: fp64 MFMAs, with `pause` x 64 clocks of s_sleep between two bursts — or until *d_stop != 0 (d_stop may be NULL).
+ * d_sink: one double of device memory.  Answers what the clock governor looks at when the shader clock drops during the
+ * replicated eigensolve (profiles/r02_clock_gap.txt). */
+int32_t jcdf_keepalive_device(void *stream, int32_t workgroups, int32_t threads, double microseconds, int32_t mode,
+                              int32_t pause, const int32_t *d_stop, double *d_sink);
 /* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
  * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
  * d_Bmat nd x nd ring buffer of error-vector dot products (row and column `head` are first overwritten with

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "jcdf_sytrd_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
     "jcdf_sytrd_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64]),
     "jcdf_sytrd_max_n": (_I64, [C.c_int32]),
+    "jcdf_keepalive_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, _P, _P]),
     "jcdf_sytrd_replay_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _I64]),
     "jcdf_sytrd2_max_n": (_I64, []),
     "jcdf_sytrd2_workspace_bytes": (_I64, [_I64]),

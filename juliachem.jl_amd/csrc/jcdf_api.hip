@@ -1349,6 +1349,17 @@ int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, i
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
+int32_t jcdf_keepalive_device(void *stream, int32_t workgroups, int32_t threads, double microseconds, int32_t mode, int32_t pause,
+                              const int32_t *d_stop, double *d_sink)
+{
+    if (workgroups < 1 || workgroups > 4096 || (threads != 64 && threads != 128 && threads != 256) || microseconds < 0.0 || microseconds > 1.0e6 ||
+        mode < 0 || mode > 2 || pause < 0 || pause > 127 || !d_sink)
+        return JCDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_keepalive, dim3((unsigned)workgroups), dim3((unsigned)threads), 0, (hipStream_t)stream,
+                       (unsigned long long)(microseconds * 100.0), (int)mode, (const int *)d_stop, d_sink, (int)pause);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
 int64_t jcdf_sytrd_max_n(int32_t with_q)
 {
     int64_t n = 64;

@@ -140,4 +140,31 @@ __global__ __launch_bounds__(256) void k_trsm_small(const double *__restrict__ L
     }
 }
 
+// ---- k_keepalive: waves that keep the CUs occupied for a given time (experiment: what the clock governor looks at) ----------
+// After ~1 ms without load on most CUs (the replicated eigensolve: 64 polling workgroups) the next Fock build runs 11-17 %
+// slower at IDENTICAL cycle counts per phase (tools/w_stall.py with W_STALL_GAP_MS): the shader clock has dropped and climbs
+// back over several ms.  mode 0: the waves only sleep (occupancy without issue), 1: a dependent fp64 FMA chain per wave,
+// 2: fp64 MFMAs back to back.  `until` = wall-clock ticks (100 MHz) to stay; `stop` (optional): leave as soon as *stop != 0.
+__global__ __launch_bounds__(256) void k_keepalive(unsigned long long ticks, int mode, const int *stop, double *sink, int pause)
+{
+    const unsigned long long t0 = wall_clock64();
+    double x = 1.0 + threadIdx.x * 1e-9;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (;;) {
+        if (mode == 0) {
+            __builtin_amdgcn_s_sleep(127);
+        } else if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) x = x * 1.0000001 + 1e-12;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+        }
+        for (int i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(1);    // duty cycle: `pause` x 64 clocks between two bursts
+        if (wall_clock64() - t0 >= ticks) break;
+        if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    }
+    if (x + acc[0] == 123.456) sink[0] = x;                          // keeps the arithmetic alive
+}
+
 }  // namespace jcdf

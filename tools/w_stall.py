@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where the waves of the W kernel spend their cycles: s_memtime stamps around the five segments of a
 phase in a diagnostic build of k_exchange_W_dma (template bit 32), C20H42 shape, 6 MFMA row tiles.
-usage (GPU box): JCDF_W_ABLATE=32 JCDF_W_REM=0 python tools/w_stall.py"""
+usage (GPU box): JCDF_W_ABLATE=32 JCDF_W_REM=0 python tools/w_stall.py
+W_STALL_GAP_MS=3: every build is preceded by that many ms of idle device (the state a build meets inside the SCF loop)."""
 import os, sys
 os.environ.setdefault("JCDF_W_ABLATE", "32"); os.environ.setdefault("JCDF_W_REM", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,9 +24,16 @@ for s0 in range(0, Q, 256):
     fb.push_three_center_device(s0, s1, (0.5 * (A + A.transpose(0, 1))).contiguous().reshape(-1))
 C, _ = np.linalg.qr(rng.standard_normal((N, N)))
 Ct = torch.as_tensor(np.ascontiguousarray(C[:, :o].T), device=dev)
+import time
+gap = float(os.environ.get("W_STALL_GAP_MS", "0")) * 1e-3
 for _ in range(10):
+    if gap > 0:
+        torch.cuda.synchronize()
+        time.sleep(gap)
     fb.build(Ct)
 torch.cuda.synchronize()
+if gap > 0:
+    print("(every build after %.1f ms of idle device)" % (gap * 1e3))
 ks = {k["name"]: k["seconds"] * 1e3 for k in fb.h.kernel_stats()}
 lib = jc._lib.load()
 buf = np.zeros((200000, 6), dtype=np.uint64)
