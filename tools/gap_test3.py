@@ -46,6 +46,10 @@ def pre(mode):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); eig(S); e1.record()
         eig_ms.append((e0, e1))
+    elif mode.startswith("eig, burst"):
+        # how long must the activity last?  eigensolve, then FMA chains on every CU for so many microseconds, then the build
+        eig(S)
+        keep(main, float(mode.split()[-1]), 1)
     elif mode.startswith("eig+keep"):
         # keep-alive waves beside the eigensolve until it is done: mode, workgroups, threads, pause
         _, m, wg, thr, pause = mode.split()
@@ -61,10 +65,14 @@ def pre(mode):
 
 
 modes = ["back-to-back", "idle 3 ms", "keepalive 0", "keepalive 1", "keepalive 2", "eigensolve"]
+modes += ["eig, burst %d" % us for us in (50, 100, 200, 400, 800, 1600)]
+if os.environ.get("GAP3_SHORT"):
+    modes = ["back-to-back", "eigensolve"] + ["eig, burst %d" % us for us in (50, 100, 200, 400, 800, 1600)]
 for m in (1, 2):
     for wg, thr in ((256, 64), (512, 64), (256, 256), (512, 256)):
         for pause in (0, 16):
-            modes.append("eig+keep %d %d %d %d" % (m, wg, thr, pause))
+            if not os.environ.get("GAP3_SHORT"):
+                modes.append("eig+keep %d %d %d %d" % (m, wg, thr, pause))
 modes.append("back-to-back")
 for mode in modes:
     for _ in range(5): fb.build(Ct)
