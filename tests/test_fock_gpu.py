@@ -368,6 +368,34 @@ def test_water_golden_energy_trail_on_gpu():
     fb.close()
 
 
+@pytest.mark.parametrize("env", ["JCDF_EIGH_TWO_STAGE", "JCDF_EIGH_Q_REPLAY"])
+def test_water_golden_trail_with_the_optional_eigensolver_paths(env, monkeypatch):
+    """The reference's water / cc-pVDZ SCF trail (golden log) with the two optional forms of the replicated eigensolve — the
+    two-stage reduction, and Q rebuilt from the stored reflectors on a side stream — inside the device SCF loop."""
+    import torch
+    from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
+    from water_case import water
+    monkeypatch.setenv(env, "1")
+    w = water()
+    g = w["golden"]
+    fb = DeviceFockBuilder(25, 96, w["n_occ"], w["aux_shell_nbas"], device=0)
+    fb.set_metric(w["J2c"])
+    fb.set_core_hamiltonian(w["H"])
+    fb.exchange_three_center(torch.as_tensor(np.ascontiguousarray(w["T3"].transpose(2, 1, 0)), device=fb.device).reshape(-1))
+    scf = DeviceSCF(fb, w["H"], w["S"], w["E_nuc"])
+    assert scf.eigh.ok and (scf.eigh.two_stage if env == "JCDF_EIGH_TWO_STAGE" else scf.eigh.q_replay)
+    for it in range(1, 60):
+        E, dE, drms = scf.step()
+        if abs(dE) <= 1e-6 and drms <= 1e-6:
+            break
+    assert it == len(g["trail"]) + 1
+    for (i1, e1, d1, r1), (i2, e2, d2, r2) in zip(scf.trail, g["trail"]):
+        assert i1 == i2 and abs(e1 - e2) < 2e-8 and abs(r1 - r2) < 1e-8, (scf.trail[i1 - 1], g["trail"][i1 - 1])
+    assert abs(E - g["final_energy"]) < 1e-9
+    assert scf.solver_report()["vendor_fallbacks"] == 0
+    fb.close()
+
+
 @pytest.mark.parametrize("n,ormtr", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
                                      (1250, 0), (64, 1), (130, 1), (510, 1), (64, 2), (510, 2)])
 def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
