@@ -1303,8 +1303,10 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     // one exchange per column (every workgroup forms the reflector itself) wins while the redundant work is small:
     // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
     static const int onehop_env = getenv("JCDF_SYTRD_ONEHOP") ? atoi(getenv("JCDF_SYTRD_ONEHOP")) : -1;
-    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 640;
-    if (onehop && n <= 640) {
+    // (with every poll of a thread in flight at once, sub_two_n, the one-exchange kernel also wins at n = 700: 3.86 vs 3.98 ms and
+    //  956: 5.86 vs 6.11 ms; at n = 1250 the two-exchange kernel with 512 threads stays ahead: 8.70 vs 8.89 ms)
+    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1000;
+    if (onehop && n <= 1000) {
         const int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
         const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
 #define JCDF_ONEHOP(NR)                                                                                                     \
@@ -1316,7 +1318,8 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         if (n <= 64) JCDF_ONEHOP(2);
         else if (n <= 256) JCDF_ONEHOP(8);
         else if (n <= 512) JCDF_ONEHOP(16);
-        else JCDF_ONEHOP(20);
+        else if (n <= 640) JCDF_ONEHOP(20);
+        else JCDF_ONEHOP(32);
 #undef JCDF_ONEHOP
         return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
     }

@@ -439,33 +439,63 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
 }
 
 // ---- the same, two buffers polled together (one round trip): pairs of both, + optional heartbeat ---------------
+// NB = pairs-per-buffer a thread takes (count <= 2 NB blockDim): ALL of them are in flight at once — one poll round trip per
+// step, not one per pair (with three sequential rounds per step the one-exchange kernel lost to the two-exchange kernel
+// above n ~ 700).
+template <int NB>
+__device__ __forceinline__ bool sub_two_n(const u64 *g1, unsigned tag1, double *dst1, const u64 *g2, unsigned tag2, double *dst2,
+                                          int count, int *err, const u64 *beat, unsigned btag)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    unsigned pending[NB];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int i0 = 2 * tid + 2 * nthr * e;
+        pending[e] = 0u;
+        if (i0 < count) pending[e] |= 1u | (g2 ? 4u : 0u);
+        if (i0 + 1 < count) pending[e] |= 2u | (g2 ? 8u : 0u);
+        any = any || pending[e] != 0u;
+    }
+    bool hb_pending = beat != nullptr;
+    unsigned spins = 0;
+    u64 t0 = 0;
+    while (any || hb_pending) {
+        u64 a0[NB], a1[NB], b0[NB], b1[NB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int i0 = 2 * tid + 2 * nthr * e;
+            a0[e] = (pending[e] & 1u) ? __hip_atomic_load(g1 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            a1[e] = (pending[e] & 2u) ? __hip_atomic_load(g1 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            b0[e] = (pending[e] & 4u) ? __hip_atomic_load(g2 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            b1[e] = (pending[e] & 8u) ? __hip_atomic_load(g2 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+        const u64 hb = hb_pending ? __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        any = false;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int i0 = 2 * tid + 2 * nthr * e;
+            if ((pending[e] & 1u) && (unsigned)(a0[e] & 3ULL) == tag1) { dst1[i0] = __longlong_as_double((long long)(a0[e] & ~3ULL)); pending[e] &= ~1u; }
+            if ((pending[e] & 2u) && (unsigned)(a1[e] & 3ULL) == tag1) { dst1[i0 + 1] = __longlong_as_double((long long)(a1[e] & ~3ULL)); pending[e] &= ~2u; }
+            if ((pending[e] & 4u) && (unsigned)(b0[e] & 3ULL) == tag2) { dst2[i0] = __longlong_as_double((long long)(b0[e] & ~3ULL)); pending[e] &= ~4u; }
+            if ((pending[e] & 8u) && (unsigned)(b1[e] & 3ULL) == tag2) { dst2[i0 + 1] = __longlong_as_double((long long)(b1[e] & ~3ULL)); pending[e] &= ~8u; }
+            any = any || pending[e] != 0u;
+        }
+        if (hb_pending && (unsigned)(hb & 3ULL) == btag) hb_pending = false;
+        if (!any && !hb_pending) break;
+        if (!spin_ok(spins, t0, err)) return false;
+    }
+    return true;
+}
+
 __device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *dst1, const u64 *g2, unsigned tag2, double *dst2,
                                         int count, int *err, const u64 *beat, unsigned btag)
 {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    bool ok = true;
-    for (int i0 = 2 * tid, first = 1; (i0 < count || first) && ok; i0 += 2 * nthr, first = 0) {
-        unsigned pending = (first && beat) ? 16u : 0u;
-        if (i0 < count) pending |= 1u | (g2 ? 4u : 0u);
-        if (i0 + 1 < count) pending |= 2u | (g2 ? 8u : 0u);
-        unsigned spins = 0;
-        u64 t0 = 0;
-        while (pending) {
-            const u64 a0 = (pending & 1u) ? __hip_atomic_load(g1 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const u64 a1 = (pending & 2u) ? __hip_atomic_load(g1 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const u64 b0 = (pending & 4u) ? __hip_atomic_load(g2 + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const u64 b1 = (pending & 8u) ? __hip_atomic_load(g2 + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const u64 hb = (pending & 16u) ? __hip_atomic_load(beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            if ((pending & 1u) && (unsigned)(a0 & 3ULL) == tag1) { dst1[i0] = __longlong_as_double((long long)(a0 & ~3ULL)); pending &= ~1u; }
-            if ((pending & 2u) && (unsigned)(a1 & 3ULL) == tag1) { dst1[i0 + 1] = __longlong_as_double((long long)(a1 & ~3ULL)); pending &= ~2u; }
-            if ((pending & 4u) && (unsigned)(b0 & 3ULL) == tag2) { dst2[i0] = __longlong_as_double((long long)(b0 & ~3ULL)); pending &= ~4u; }
-            if ((pending & 8u) && (unsigned)(b1 & 3ULL) == tag2) { dst2[i0 + 1] = __longlong_as_double((long long)(b1 & ~3ULL)); pending &= ~8u; }
-            if ((pending & 16u) && (unsigned)(hb & 3ULL) == btag) pending &= ~16u;
-            if (!pending) break;
-            if (!spin_ok(spins, t0, err)) { ok = false; break; }
-        }
-    }
-    return ok;
+    const int per = 2 * (int)blockDim.x;
+    if (count <= per) return sub_two_n<1>(g1, tag1, dst1, g2, tag2, dst2, count, err, beat, btag);
+    if (count <= 2 * per) return sub_two_n<2>(g1, tag1, dst1, g2, tag2, dst2, count, err, beat, btag);
+    if (count <= 3 * per) return sub_two_n<3>(g1, tag1, dst1, g2, tag2, dst2, count, err, beat, btag);
+    return sub_two_n<4>(g1, tag1, dst1, g2, tag2, dst2, count, err, beat, btag);      // count <= 8 blockDim
 }
 
 // ---- k_sytrd_onehop: ONE all-to-all exchange per column (experimental twin of k_sytrd_lower, same interface) -----

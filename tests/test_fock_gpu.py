@@ -397,7 +397,7 @@ def test_water_golden_trail_with_the_optional_eigensolver_paths(env, monkeypatch
 
 
 @pytest.mark.parametrize("n,ormtr", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
-                                     (1250, 0), (64, 1), (130, 1), (510, 1), (64, 2), (510, 2)])
+                                     (956, 0), (1000, 0), (1001, 0), (1250, 0), (64, 1), (130, 1), (510, 1), (64, 2), (510, 2)])
 def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     """Persistent-kernel tridiagonalisation (+ in-kernel Q accumulation and one GEMM, or ormtr) + stedc
     vs numpy (LAPACK) eigh."""

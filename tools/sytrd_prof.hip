@@ -26,10 +26,12 @@ int main(int argc, char **argv)
     const int nthr = argc > 5 ? atoi(argv[5]) : 256;
     const int onehop = argc > 6 ? atoi(argv[6]) : 0;             // 1: k_sytrd_onehop
     const size_t lds = onehop ? ((size_t)ncol * n + 5 * n + 32) * 8 : ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
-    if (onehop && (ncol > 8 || n > 640)) { printf("onehop needs <= 8 columns per workgroup and n <= 640\n"); return 1; }
+    if (onehop && (ncol > 8 || n > 1280)) { printf("onehop needs <= 8 columns per workgroup and n <= 1280\n"); return 1; }
     double *dQ; hipMalloc(&dQ, A.size() * 8);
     hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void *)k_sytrd_onehop<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)k_sytrd_onehop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)k_sytrd_onehop<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
         hipMemset(w, 0, wb);
@@ -37,7 +39,13 @@ int main(int argc, char **argv)
         hipMemcpyToSymbol(HIP_SYMBOL(g_sytrd_prof), zero, sizeof(zero));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        if (onehop)
+        if (onehop && n > 1024)
+            hipLaunchKernelGGL(k_sytrd_onehop<40>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
+                               (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
+        else if (onehop && n > 640)
+            hipLaunchKernelGGL(k_sytrd_onehop<32>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
+                               (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
+        else if (onehop)
             hipLaunchKernelGGL(k_sytrd_onehop<20>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
                                (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
         else
