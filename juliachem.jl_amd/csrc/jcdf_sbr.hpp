@@ -74,31 +74,6 @@ __device__ __forceinline__ double pair_sum16(double a, double b)
     return mk_f64(l[0], h[0]) + mk_f64(l[1], h[1]);
 }
 
-// dlarfg scalars without IEEE division / square root (their expansions are ~25 dependent instructions each and this
-// chain is on the critical path of every step): y = rsqrt(alpha^2 + sigma) and r = 1 / (|alpha| + norm) by the
-// hardware estimates + two Newton steps (full double precision), then
-//   beta = -sign(alpha) norm,  tau = (beta - alpha) / beta = 1 + |alpha| y,  scale = 1 / (alpha - beta) = sign(alpha) r.
-__device__ __forceinline__ void house_scalars(double alpha, double sigma, double &tau, double &beta, double &scale)
-{
-    tau = 0.0;
-    beta = alpha;
-    scale = 0.0;
-    if (sigma != 0.0) {
-        const double x = alpha * alpha + sigma;
-        double y = __builtin_amdgcn_rsq(x);
-        y = y * (1.5 - 0.5 * x * y * y);
-        y = y * (1.5 - 0.5 * x * y * y);
-        const double norm = x * y, aa = fabs(alpha);
-        const double dn = aa + norm;
-        double r = __builtin_amdgcn_rcp(dn);
-        r = r * (2.0 - dn * r);
-        r = r * (2.0 - dn * r);
-        beta = -copysign(norm, alpha);
-        tau = 1.0 + aa * y;
-        scale = copysign(r, alpha);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // stage 1
 // ---------------------------------------------------------------------------------------------------------------
