@@ -4,16 +4,18 @@
 // Why two stages: the one-stage Householder reduction (jcdf_eig.hpp) needs one chip-wide exchange per COLUMN — n
 // dependent all-to-all hand-offs at 4.6-7 us each, 2.4 ms at n = 510, the largest single item of an SCF iteration.
 //   stage 1  dense -> band of half-width SB = 16 (successive band reduction): per PANEL of 16 columns one Householder
-//            QR inside ONE workgroup (its column steps synchronise through LDS, ~0.4 us each) and one two-sided
+//            QR inside ONE workgroup (its column steps synchronise through LDS; measured 1.2 us each) and one two-sided
 //            block-reflector update A22 <- (I - V T V^T)^T A22 (I - V T V^T) = A22 - V W^T - W V^T on MFMA;
 //            the chip-wide dependencies drop from n to 3 n/16 kernel boundaries;
 //   stage 2  band -> tridiagonal by bulge chasing, one column per sweep, in ONE workgroup: the band (n x 2 SB
 //            doubles) lives in LDS, every wave owns a sweep and follows the sweep in front of it at the classical
-//            distance of two blocks; the waves synchronise through progress counters in LDS (~0.1 us, no
-//            chip-wide traffic at all);
-//   Q        the orthogonal factor is accumulated forwards, row-wise: Q1 = prod (I - V T V^T) inside the stage-1
-//            update launch, then the stage-2 reflectors are replayed from a log on the rows of Q1 by a third kernel
-//            that can run beside the tridiagonal eigensolver (it needs only D and E).
+//            distance of two blocks; the waves synchronise through progress counters in LDS (no chip-wide traffic
+//            at all); measured: bound by the instruction issue of that one CU, 1.0 ms at n = 510;
+//   Q        the orthogonal factor is accumulated forwards, row-wise: Q1 = prod (I - V T V^T) by one kernel per panel on
+//            a side stream beside the chase, then the stage-2 reflectors are replayed from a log on the rows of Q1 by a
+//            kernel that runs beside the tridiagonal eigensolver (it needs only D and E).
+// Result (profiles/r02_two_stage_eigh.txt): on par with the one-stage kernel at n <= 590 (2.72-2.79 vs 2.74 ms per
+// eigensolve at n = 510), not faster — optional (DeviceEigh: JCDF_EIGH_TWO_STAGE=1), the one-stage kernel is the default.
 // tools/sbr_proto.py is the numpy statement of the same algorithm with the same index conventions.
 #pragma once
 #include <hip/hip_runtime.h>
