@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — DF-RHF SCF iterations/s + Fock-build TFLOP/s on MI355X.
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W; for N > 1 it
-is launched with torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints
-ONE JSON line.
+Contract (driver): python bench.py --gpus N --steps K --warmup W; for N > 1 the
+driver launches it with torch.distributed.run, one rank per GPU (RCCL) — and a plain
+`python bench.py --gpus N` starts those N ranks itself as a child process before it
+touches torch or HIP (launch_ranks).  WORLD_SIZE != --gpus is fatal (exit 2): a line
+whose n_gpus differs from what was asked for is never printed.  Rank 0 prints ONE
+JSON line.
 
 Workload = BASELINE.json metric config: C20H42 / cc-pVDZ (+ cc-pVDZ-RIFIT),
 N = 510 AO, Q = 1950 aux, 81 occupied, synthetic tensors of that
@@ -247,7 +250,7 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -258,27 +261,83 @@ def main():
     ap.add_argument("--no-real", action="store_true", help="skip the real_molecule object (profiling runs)")
     ap.add_argument("--density-solver", default="eigh", choices=["eigh", "sp2"],
                     help="eigh: the reference's eigensolve per iteration (default, what `value` is quoted on); sp2: spectral projection")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD process
+    (torch.distributed.run, one rank per GPU) — this process has not imported torch or touched HIP, and it never execs.
+    Rank 0's JSON line is relayed on stdout, everything else on stderr; the child's return code is ours.  torchrun tears
+    the other ranks down when one of them fails."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the %d-rank child printed %d JSON lines (expected 1)\n" % (args.gpus, lines))
+        rc = 3
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args, argv))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        # a record that says n_gpus = 1 for a run asked to use 8 (or the reverse) must never exist
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or drop the launcher: "
+                         "bench.py starts its own ranks)\n" % (args.gpus, world, args.gpus))
+        raise SystemExit(2)
 
     import torch
     import juliachem_jl_amd as jc
     from juliachem_jl_amd import synthetic
     from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("JCDF_BENCH_BACKEND", "nccl")      # "gloo": host-staged rehearsal on a 1-GPU box
+        # a rank that dies must not leave the others waiting in a collective for ever
+        limit = datetime.timedelta(seconds=int(os.environ.get("JCDF_BENCH_TIMEOUT_S", "900")))
+        ndev = torch.cuda.device_count()
         if backend == "gloo":
-            local = local % max(1, torch.cuda.device_count())
+            local = local % max(1, ndev)
             torch.cuda.set_device(local)
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
+            if local >= ndev:
+                sys.stderr.write("bench.py: rank %d needs GPU %d but the node shows %d (JCDF_BENCH_BACKEND=gloo shares one GPU)\n"
+                                 % (rank, local, ndev))
+                raise SystemExit(2)
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=limit)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
 

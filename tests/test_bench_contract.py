@@ -53,6 +53,53 @@ def test_bench_prints_the_contract_line():
     assert d["alt"]["density_solver"] == "sp2" and d["alt"]["value"] > 50.0 and abs(d["alt"]["energy_minus_eigh"]) < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks():
+    """A plain `python bench.py --gpus 2` (no launcher around it) is a 2-rank job: bench.py starts torch.distributed.run as a
+    child before touching torch / HIP.  On the one-GPU box both ranks share the card and the collectives are host-staged
+    (JCDF_BENCH_BACKEND=gloo): timings mean nothing here, the record's shape does."""
+    env = dict(os.environ, JCDF_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-real"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["allreduce_ms"] > 0.0 and d["scaling"] == "strong"
+    w50 = d["scaling_w50"]
+    assert w50 is not None and w50["screened_13pct"]["allreduce_ms"] > 0.0
+    assert w50["screened_13pct"]["aux_rows_rank0"] < 4800          # rank 0 holds a shard of the aux index, not all of it
+    assert "cpu_baseline" not in d and "real_molecule" not in d
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 2 inside a 1-rank world (or the reverse) exits non-zero before anything is measured (no GPU needed)."""
+    for gpus, world in (("2", "1"), ("1", "2")):
+        env = dict(os.environ, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert "WORLD_SIZE" in r.stderr
+
+
+def test_bench_child_failure_is_relayed():
+    """launch_ranks hands the child's return code on and prints no JSON line when the ranks fail (here: no GPU, so every
+    rank exits non-zero; on a GPU box the test_bench_gpus_2 case covers the success side)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("failure side is exercised on the GPU-less box")
+    env = dict(os.environ, JCDF_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-real", "--no-w50"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_cpu_baseline_object_shape():
     """The cpu_baseline leg (the oracle on the host cores) on a tiny shape: keys of the contract."""
     sys.path.insert(0, ROOT)
