@@ -7,7 +7,7 @@ mkdir -p "$PKG/lib" "$ROOT/oracle/_build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread \
     -Wall -Wno-unused-function \
-    -I"$ROOT/include" \
+    -I"$ROOT/include" -Wl,--version-script="$PKG/csrc/exports.map" \
     "$PKG/csrc/jcdf_api.hip" "$PKG/csrc/jcint_host.cpp" -o "$PKG/lib/libjcdf_hip.so" "$@"
 gcc -O2 -fPIC -shared -o "$ROOT/oracle/_build/libjcdf_oracle.so" "$ROOT/oracle/c/jcdf_oracle.c"
 # CPU baseline of bench.py (the reference's two CPU modes on the host BLAS found at run time); checker/bench code only

@@ -107,13 +107,22 @@ int32_t jcdf_abi_version(void);
 int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, int64_t q1,
                        int64_t n_occ, int64_t P, const int64_t *pq_p, const int64_t *pq_q);
 
+/* Tuning knobs a caller may set (the library reads NO environment variable).  Call before jcdf_configure; values persist
+ * across jcdf_configure; 0 restores the library's own rule.  Keys:
+ *   "k_slices_per_xcd"  split-K slices of the exchange-K SYRK per XCD (the reference's df_exchange_n_blocks plays this role,
+ *                       GPUDF.jl:61-72; results do not depend on it beyond summation order)
+ *   "w_chunk_stages"    contraction stages per workgroup chunk of the exchange-W kernel
+ *   "host_cholesky"     1: factor the metric with the library's host potrf/trtri instead of on the device
+ * JCDF_ERR_INVALID for an unknown key or a value out of range. */
+int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value);
+
 /* Metric.  `J2c` = two_center_integrals (Q_total x Q_total column-major, only the
  * lower triangle is read, TwoCenterIntegrals.jl:7-29).  Performs potrf('L') +
  * trtri('L','N') ON THE DEVICE (blocked fp64-MFMA factorisation, csrc/jcdf_chol.hpp —
  * the placement of CUSOLVER.potrf!/trtri! at DenseGPUDF.jl:185-193; the screened
  * path does it with host LAPACK at GPUDF.jl:890-891) and keeps rows [q0,q1) of
- * L^-1.  JCDF_ERR_NOT_SPD on a non-positive pivot.  Environment JCDF_HOST_CHOLESKY=1
- * selects the library's host potrf/trtri instead (debug). */
+ * L^-1.  JCDF_ERR_NOT_SPD on a non-positive pivot.  jcdf_set_tuning(h, "host_cholesky", 1)
+ * selects the library's host potrf/trtri instead (the reference's GPUDF.jl:890-891 placement). */
 int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c);
 /* Same, when the caller already holds L^-1 (Q_total x Q_total, lower
  * triangular, upper = 0) — what GPUDF.jl:893-902 uploads / broadcasts. */
@@ -165,7 +174,7 @@ int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_
  * the W pass: by default J is enqueued on an internal side stream and runs BESIDE K (forked and joined with events
  * on the build's stream; 3.3 -> 3.1 ms per build on the C20H42 shape).  overlap_jk = 0 runs them one after the
  * other — then J_time / K_time of jcdf_timings are the stand-alone durations the rooflines are quoted on; with the
- * overlap J_time is the (longer) time J takes while it shares the device.  Environment JCDF_OVERLAP_JK=0/1 overrides. */
+ * overlap J_time is the (longer) time J takes while it shares the device. */
 int32_t jcdf_set_overlap(jcdf_handle *h, int32_t overlap_jk);
 /* Blocks until work enqueued by the previous call has finished; fills timings. */
 int32_t jcdf_synchronize(jcdf_handle *h, jcdf_timings *t);
@@ -204,33 +213,6 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
-/* Q of A = Q T Q^T rebuilt from the reflectors jcdf_sytrd_device left in d_A / d_TAU (LAPACK dorgtr's matrix, row-major,
- * leading dimension ldq), row-parallel; n <= 640.  It needs neither D nor E: the caller runs it on a second stream beside
- * jcdf_stedc_device, so that the persistent kernel spends its hand-off window on the rank-2 update instead of on Q. */
-int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU,
-                                   double *d_Q, int64_t ldq);
-/* The same reduction in two stages (csrc/jcdf_sbr.hpp): dense -> band of half-width 16 (one Householder QR per panel of
- * 16 columns inside one workgroup + MFMA block-reflector updates) -> tridiagonal (bulge chasing in the LDS of one
- * workgroup) — 3 n/16 kernel boundaries instead of n chip-wide hand-offs.  jcdf_sytrd2_device leaves D, E (device, n and
- * n-1), the stage-1 orthogonal factor in d_Q (n x n row-major, leading dimension ldq) and the stage-2 reflectors in
- * d_work; jcdf_sytrd2_apply_q_device (any stream ordered behind the first call; it needs neither D nor E, so it may run
- * beside jcdf_stedc_device) completes d_Q to the Q of A = Q T Q^T.  d_A (symmetric, fully stored) is overwritten.
- * The int at byte offset 8 of d_work is non-zero afterwards if a wait inside the chase gave up (result invalid).
- * n <= jcdf_sytrd2_max_n() (the band must fit the LDS of one CU: 590).  The stage-1 factor is accumulated on an internal
- * per-device side stream beside the chase and joined into `stream` before the call returns: one call at a time per device. */
-int64_t jcdf_sytrd2_max_n(void);
-int64_t jcdf_sytrd2_workspace_bytes(int64_t n);
-int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_Q,
-                           int64_t ldq, void *d_work, int64_t work_bytes);
-int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t ldq, const void *d_work,
-                                   int64_t work_bytes);
-/* Experiment helper (tools/gap_test3.py; not on any product path): `workgroups` workgroups of `threads` (64 / 128 / 256)
- * threads that stay on the device for `microseconds` — mode 0: sleeping waves only, 1: a dependent fp64 FMA chain per wave,
- * 2: fp64 MFMAs, with `pause` x 64 clocks of s_sleep between two bursts — or until *d_stop != 0 (d_stop may be NULL).
- * d_sink: one double of device memory.  Answers what the clock governor looks at when the shader clock drops during the
- * replicated eigensolve (profiles/r02_clock_gap.txt). */
-int32_t jcdf_keepalive_device(void *stream, int32_t workgroups, int32_t threads, double microseconds, int32_t mode,
-                              int32_t pause, const int32_t *d_stop, double *d_sink);
 /* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
  * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
  * d_Bmat nd x nd ring buffer of error-vector dot products (row and column `head` are first overwritten with
@@ -294,11 +276,6 @@ int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double 
 int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots,
                               double *d_work /* 64 * nd doubles */);
 int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F);
-
-/* Diagnostic only (environment JCDF_W_ABLATE=32 with JCDF_W_REM=0 at jcdf_configure, 81..96 occupied orbitals): shader
- * cycles per wave spent in the five segments of the W kernel's phases during the last build — DMA issue, operand reads +
- * MFMA issue, index loads / epilogue, counted vmcnt wait, barrier — and the number of phases; 6 words per wave. */
-int64_t jcdf_w_stall_cycles(jcdf_handle *h, unsigned long long *out, int64_t max_waves);
 
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */

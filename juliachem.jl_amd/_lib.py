@@ -10,6 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JCDF_LIB_PATH") or os.path.join(_HERE, "lib", "libjcdf_hip.so")   # (override: diagnostic builds of tools/)
 
 
+def is_diagnostic_build() -> bool:
+    """True when the loaded library is a -DJCDF_DIAGNOSTIC build (tools/build_diag.sh): experiment entry points present."""
+    return hasattr(load(), "jcdf_sytrd2_device")
+
+
 class JCDFError(RuntimeError):
     """A non-zero jcdf_* status, converted the way the Julia glue converts it
     to error() (reference convention: GPUDF.jl:39-41)."""
@@ -42,6 +47,7 @@ PROTOTYPES = {
     "jcdf_abi_version": (C.c_int32, []),
     "jcdf_set_stream": (C.c_int32, [_P, _P, C.c_int32]),
     "jcdf_configure": (C.c_int32, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
+    "jcdf_set_tuning": (C.c_int32, [_P, C.c_char_p, _I64]),
     "jcdf_set_metric": (C.c_int32, [_P, _P]),
     "jcdf_set_metric_inverse": (C.c_int32, [_P, _P]),
     "jcdf_push_three_center": (C.c_int32, [_P, _I64, _I64, _P]),
@@ -64,12 +70,6 @@ PROTOTYPES = {
     "jcdf_sytrd_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
     "jcdf_sytrd_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64]),
     "jcdf_sytrd_max_n": (_I64, [C.c_int32]),
-    "jcdf_keepalive_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, _P, _P]),
-    "jcdf_sytrd_replay_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _I64]),
-    "jcdf_sytrd2_max_n": (_I64, []),
-    "jcdf_sytrd2_workspace_bytes": (_I64, [_I64]),
-    "jcdf_sytrd2_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64]),
-    "jcdf_sytrd2_apply_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _I64]),
     "jcdf_diis_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "jcdf_stedc_workspace_bytes": (_I64, [_I64]),
     "jcdf_stedc_device": (C.c_int32, [_P, _I64, _P, _P, _P, _I64, _P, _I64]),
@@ -82,10 +82,20 @@ PROTOTYPES = {
     "jcdf_diis_push_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P]),
     "jcdf_diis_dots_device": (C.c_int32, [_P, C.c_int32, C.c_int32, _I64, _P, _P, _P]),
     "jcdf_diis_mix_device": (C.c_int32, [_P, C.c_int32, _I64, _I64, _P, _P, _P]),
-    "jcdf_w_stall_cycles": (_I64, [_P, _P, _I64]),
     "jcdf_device_bytes": (_I64, [_P]),
     "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),
     "jcdf_kernel_stats_total": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
+}
+
+# entry points of DIAGNOSTIC builds only (csrc/jcdf_diag.h; tools/build_diag.sh + JCDF_LIB_PATH): bound when present
+DIAG_PROTOTYPES = {
+    "jcdf_keepalive_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, _P, _P]),
+    "jcdf_sytrd_replay_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _I64]),
+    "jcdf_sytrd2_max_n": (_I64, []),
+    "jcdf_sytrd2_workspace_bytes": (_I64, [_I64]),
+    "jcdf_sytrd2_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64]),
+    "jcdf_sytrd2_apply_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _I64]),
+    "jcdf_w_stall_cycles": (_I64, [_P, _P, _I64]),
 }
 
 _lib = None
@@ -109,5 +119,10 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DIAG_PROTOTYPES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = lib
     return _lib

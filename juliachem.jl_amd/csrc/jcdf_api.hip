@@ -12,7 +12,11 @@
 #include "jcdf_sp2.hpp"
 #include "jcdf_scf.hpp"
 #include "jcdf_blas.hpp"
+#ifdef JCDF_DIAGNOSTIC            // tools/build_diag.sh: ablations, experiment kernels and the variant knobs; never in the shipping library
+#include "jcdf_kernels_diag.hpp"
 #include "jcdf_sbr.hpp"
+#include "jcdf_diag.h"
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -31,6 +35,14 @@ namespace {
 std::string g_create_error;
 
 inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Variant / experiment knobs are environment variables of DIAGNOSTIC builds only (-DJCDF_DIAGNOSTIC, tools/build_diag.sh);
+// the shipping library reads no environment: what a caller may tune goes through jcdf_set_tuning.
+#ifdef JCDF_DIAGNOSTIC
+inline const char *diag_env(const char *name) { return getenv(name); }
+#else
+inline const char *diag_env(const char *) { return nullptr; }
+#endif
 
 struct KernelRec {
     const char *name;
@@ -54,14 +66,16 @@ struct jcdf_handle {
     int WMw = 0, WVMw = 1, n_mtiles = 0, opad = 0, n_qt = 0, vld = 0;
     int w_rem = 0;                      // trailing orbitals (n_occ mod 16) contracted by VALU FMAs in the DMA W kernel
     int n_chunks = 0, n_stages = 0;
-    int w_ablate = 0;                  // timing-only ablation bits of the DMA kernel (JCDF_W_ABLATE; never set in production)
+    int w_ablate = 0;                  // diagnostic builds: timing-only ablation bits of the DMA kernel (JCDF_W_ABLATE)
     bool w_skip_partial = true;        // DMA kernel: waves past the end of the aux rows (partial last tile) issue no MFMA
-    bool w_dma = true;                 // W kernel with LDS-DMA staging (k_exchange_W_dma) or register staging (k_exchange_W)
+    bool w_dma = true;                 // LDS-DMA staging (k_exchange_W_dma); false only in diagnostic builds (register-staged k_exchange_W)
     int tq = TILE_Q;                   // aux-index tile of the W kernel: 128, or 256 for the DMA kernel up to 96 orbitals
     int kcw = KCD;                     // slots per stage of the W kernel's stage table (8 resp. 16)
     int ntri = 0, S = 0, KS = 0;
     bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
     bool dense_map = true;
+    // jcdf_set_tuning (persist across jcdf_configure); 0 = the library's own rule
+    int64_t tune_k_slices_per_xcd = 0, tune_w_chunk_stages = 0, tune_host_cholesky = 0;
 
     // device buffers
     double *dB = nullptr, *dCpad = nullptr, *dCv = nullptr, *dWt = nullptr, *dVpart = nullptr, *dV = nullptr;
@@ -70,7 +84,7 @@ struct jcdf_handle {
     int64_t ldl = 0, linv_rows = 0;
     int *dWchunk = nullptr, *dStgC = nullptr, *dStgQ = nullptr, *dStgP = nullptr;   // stage table of the W kernel
     int *dJrow = nullptr, *dCmap = nullptr;              // packed rows with q >= p; (q,p) -> index into J
-    unsigned long long *dStall = nullptr;                // JCDF_W_ABLATE=32: per-wave segment cycles of the W kernel (diagnostic)
+    unsigned long long *dStall = nullptr;                // diagnostic builds, JCDF_W_ABLATE=32: per-wave segment cycles of the W kernel
     double *dStage = nullptr;                            // setup staging for pushed three-centre blocks, freed after setup
     int64_t stage_doubles = 0;
     int64_t bytes = 0;
@@ -175,7 +189,8 @@ hipError_t launch_W_dma_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
     return hipSuccess;
 }
 
-// timing-only ablations of the C20H42-shaped form (JCDF_W_ABLATE; see k_exchange_W_dma)
+#ifdef JCDF_DIAGNOSTIC
+// timing-only ablations of the C20H42-shaped form (JCDF_W_ABLATE; see k_exchange_W_dma): WRONG RESULTS, diagnostic builds only
 template <int ABL>
 hipError_t launch_W_ablate_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
@@ -189,6 +204,7 @@ hipError_t launch_W_ablate_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
                        h->dWchunk, h->dStgC, h->dStgQ, h->dStgP, h->w_skip_partial ? 1 : 0, h->dStall);
     return hipSuccess;
 }
+#endif
 
 // VALU remainder forms: WM full MFMA row tiles + REM trailing orbitals
 template <int WM, int REM>
@@ -218,16 +234,19 @@ hipError_t launch_W_rem(jcdf_handle *h, hipStream_t st, bool attr)
 template <int WM, int WVM>
 hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
 {
-    using Cfg = WCfg<WM, WVM>;
     if (h->w_dma && h->w_rem) {
         if constexpr (WVM == 1 && WM >= 3 && WM <= 7) return launch_W_rem<WM>(h, st, set_attr_only);
     }
+#ifndef JCDF_DIAGNOSTIC
+    return launch_W_dma_t<WM, WVM, 2>(h, st, set_attr_only);
+#else
     if (h->w_dma) {
         if constexpr (WVM == 1 && WM <= 6) {
             if (h->tq == 256) return launch_W_dma_t<WM, WVM, 4>(h, st, set_attr_only);
         }
         return launch_W_dma_t<WM, WVM, 2>(h, st, set_attr_only);
     }
+    using Cfg = WCfg<WM, WVM>;
     if (set_attr_only)
         return hipFuncSetAttribute((const void *)k_exchange_W<WM, WVM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    Cfg::SMEM_BYTES);
@@ -236,10 +255,12 @@ hipError_t launch_W_t(jcdf_handle *h, hipStream_t st, bool set_attr_only)
                        h->dCpad, h->dCv, h->dWt, h->Wld, h->dVpart, h->vld, (int)h->o, h->opad, h->n_mtiles, h->n_qt,
                        h->dWchunk, h->dStgC, h->dStgQ, h->dStgP);
     return hipSuccess;
+#endif
 }
 
 hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
 {
+#ifdef JCDF_DIAGNOSTIC
     // (the ablation forms exist for 6 MFMA row tiles without the VALU remainder: C20H42 shape with JCDF_W_REM=0)
     if (h->w_ablate && h->w_dma && !h->w_rem && h->WVMw == 1 && h->WMw == 6 && h->tq == TILE_Q) {
         switch (h->w_ablate) {
@@ -255,6 +276,7 @@ hipError_t launch_W(jcdf_handle *h, hipStream_t st, bool attr = false)
             default: break;
         }
     }
+#endif
     if (h->WVMw == 2) {
         switch (h->WMw) {
             case 5: return launch_W_t<5, 2>(h, st, attr);
@@ -362,13 +384,15 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     auto run_K = [&](size_t slot) {
         KernelRec &r = rec_begin(h, slot, "k_exchange_K", st, ok);
         const int nblk = (int)(roundup(h->S, 8) * h->ntri);
-        static const bool k_dma = [] { const char *e = getenv("JCDF_K_DMA"); return !(e && atoi(e) == 0); }();
-        if (k_dma)
-            hipLaunchKernelGGL(k_exchange_K_dma<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), K_DMA_SMEM_BYTES, st, h->dWt, h->Wld,
-                               h->ntri, h->S, h->KS, h->dKslab);
-        else
+#ifdef JCDF_DIAGNOSTIC
+        static const bool k_dma = [] { const char *e = diag_env("JCDF_K_DMA"); return !(e && atoi(e) == 0); }();
+        if (!k_dma)
             hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), GemmNT<KCfg4>::SMEM_BYTES, st, h->dWt,
                                h->Wld, h->ntri, h->S, h->KS, h->dKslab);
+        else
+#endif
+            hipLaunchKernelGGL(k_exchange_K_dma<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), K_DMA_SMEM_BYTES, st, h->dWt, h->Wld,
+                               h->ntri, h->S, h->KS, h->dKslab);
         const double nT = (double)(h->Np / TILE_P);
         // diagonal tiles: the wave that owns the upper 64 x 64 block issues no MFMA
         r.flops = 2.0 * ((double)h->ntri - 0.25 * nT) * 128.0 * 128.0 * (double)h->S * (double)h->KS;
@@ -377,8 +401,8 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         ok(hipEventRecord(r.e1, st));
     };
     // record slots stay fixed (2 = J, 3 = K) whatever the launch order
-    static const bool k_first = [] { const char *e = getenv("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
-    static const int overlap_env = [] { const char *e = getenv("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
+    static const bool k_first = [] { const char *e = diag_env("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
+    static const int overlap_env = [] { const char *e = diag_env("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
     if (overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk) {
         // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs
         if (!h->side) {
@@ -687,7 +711,9 @@ hipError_t set_device_kernel_attributes()
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (first == hipSuccess && e != hipSuccess) first = e;
     };
+#ifdef JCDF_DIAGNOSTIC
     set((const void *)k_exchange_K<KCfg4>, GemmNT<KCfg4>::SMEM_BYTES);
+#endif
     set((const void *)k_exchange_K_dma<KCfg4>, K_DMA_SMEM_BYTES);
     set((const void *)k_metric_apply, GemmNT<MCfg>::SMEM_BYTES);
     set((const void *)k_coulomb_J, 150 * 1024);
@@ -801,6 +827,25 @@ int32_t jcdf_set_stream(jcdf_handle *h, void *stream, int32_t use_own)
     return JCDF_OK;
 }
 
+int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!key || value < 0) return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: NULL key / negative value");
+    const std::string k(key);
+    if (k == "k_slices_per_xcd") {
+        if (value > 64) return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: k_slices_per_xcd in 0..64");
+        h->tune_k_slices_per_xcd = value;
+    } else if (k == "w_chunk_stages") {
+        if (value > 1 << 20) return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: w_chunk_stages too large");
+        h->tune_w_chunk_stages = value;
+    } else if (k == "host_cholesky") {
+        h->tune_host_cholesky = value != 0;
+    } else {
+        return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: unknown key '" + k + "'");
+    }
+    return JCDF_OK;
+}
+
 int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, int64_t q1, int64_t n_occ,
                        int64_t P, const int64_t *pq_p, const int64_t *pq_q)
 {
@@ -841,13 +886,13 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     // orbital (M) tiling of the W kernel: up to 128 orbitals -> one 4-wave workgroup holds them all;
     // more -> 8-wave workgroups of up to 256 orbitals (two wave rows share the staged B tile)
     h->w_rem = 0;
-    if (n_occ <= 128 || getenv("JCDF_W_NO_WVM2")) {
+    if (n_occ <= 128 || diag_env("JCDF_W_NO_WVM2")) {
         h->WVMw = 1;
         h->n_mtiles = (int)((n_occ + 127) / 128);
         h->WMw = (int)((((n_occ + h->n_mtiles - 1) / h->n_mtiles) + 15) / 16);
         // 1..3 orbitals past the last full MFMA row tile: VALU FMAs instead of a 16-row tile of padding (DMA kernel,
         // 48 <= n_occ <= 115; C20H42: 81 = 5 x 16 + 1).  JCDF_W_REM=0 pads as before.
-        const char *e = getenv("JCDF_W_REM"), *d = getenv("JCDF_W_DMA");
+        const char *e = diag_env("JCDF_W_REM"), *d = diag_env("JCDF_W_DMA");
         const int64_t r = n_occ % 16;
         if (!(e && atoi(e) == 0) && !(d && atoi(d) == 0) && h->n_mtiles == 1 && r >= 1 && r <= 3 && n_occ / 16 >= 3 && n_occ / 16 <= 7) {
             h->w_rem = (int)r;
@@ -861,16 +906,16 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     }
     h->opad = h->n_mtiles * h->WVMw * h->WMw * 16 + (h->w_rem ? 16 : 0);
     {
-        const char *e = getenv("JCDF_W_DMA");
+        const char *e = diag_env("JCDF_W_DMA");
         h->w_dma = !(e && atoi(e) == 0);
         h->kcw = h->w_dma ? KCD : KC;
-        e = getenv("JCDF_W_SKIP_PARTIAL");
+        e = diag_env("JCDF_W_SKIP_PARTIAL");
         h->w_skip_partial = !(e && atoi(e) == 0);
-        e = getenv("JCDF_W_ABLATE");
+        e = diag_env("JCDF_W_ABLATE");
         h->w_ablate = e ? atoi(e) : 0;
         // 256-wide aux tiles (each staged C row feeds twice the MFMAs) measured 25 % SLOWER up to 96 orbitals (C20H42
         // shape 2.16 vs 1.70 ms: 255 VGPRs, two waves per SIMD): only on request
-        e = getenv("JCDF_W_TQ");
+        e = diag_env("JCDF_W_TQ");
         h->tq = (h->w_dma && h->WVMw == 1 && h->WMw <= 6 && h->ldq > TILE_Q && e && atoi(e) == 256) ? 256 : TILE_Q;
     }
     h->n_qt = (int)((h->ldq + h->tq - 1) / h->tq);
@@ -916,7 +961,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
         // busy either way: sum of workgroup times / slots = kernel time (profiles/r02_w_stall.txt).
         const int64_t tiles = total_stages * h->n_qt * h->n_mtiles;
         int64_t target = std::min<int64_t>(4096 / kcw, std::max<int64_t>(256 / kcw, tiles / (6 * 2 * (int64_t)h->num_cu)));
-        if (const char *e = getenv("JCDF_W_CHUNK_STAGES")) target = std::max(1, atoi(e));
+        if (h->tune_w_chunk_stages > 0) target = h->tune_w_chunk_stages;
         wchunk.push_back(0);
         int64_t in_chunk = 0;
         for (int64_t p = 0; p < N; ++p) {
@@ -961,7 +1006,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     // workgroup per CU (N = 896, 28 tiles: m = 2 in one round 2.4 ms, m = 8 2.8 ms) and taken when the model says they win
     // (N = 1915, 120 tiles: m = 1 66 ms, m = 4 60 ms).
     const int64_t max_chunks = std::max<int64_t>(1, Ktot / (4 * KC));      // >= 4 LDS stages per slice
-    static const double K_MULTI_ROUND_CHARGE = [] { const char *e = getenv("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.0; }();
+    static const double K_MULTI_ROUND_CHARGE = [] { const char *e = diag_env("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.0; }();
     const int64_t cus_per_xcd = std::max(1, h->num_cu / 8);
     const int64_t slots_per_xcd = 2 * cus_per_xcd;
     int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ntri);
@@ -976,7 +1021,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
             if (cost <= best) { best = cost; best_m = m; }                 // ties: the finer split
         }
         if (best_m && best < 0.99 * single) per_xcd = best_m;
-        if (const char *e = getenv("JCDF_K_SLICES_PER_XCD")) per_xcd = std::max(1, atoi(e));
+        if (h->tune_k_slices_per_xcd > 0) per_xcd = h->tune_k_slices_per_xcd;
     }
     int64_t S = 8 * per_xcd;
     if (S > max_chunks) S = std::max<int64_t>(1, max_chunks);
@@ -1022,7 +1067,7 @@ int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c)
     if (!h) return JCDF_ERR_INVALID;
     if (!h->configured || !J2c) return fail(h, JCDF_ERR_INVALID, "jcdf_set_metric: configure first / NULL");
     JCDF_HIP(h, hipSetDevice(h->device));
-    if (getenv("JCDF_HOST_CHOLESKY")) {              // host potrf/trtri (the reference's GPUDF.jl:890-891 placement)
+    if (h->tune_host_cholesky) {              // host potrf/trtri (the reference's GPUDF.jl:890-891 placement)
         std::vector<double> L;
         try {
             L.assign(J2c, J2c + (size_t)(h->Qtot * h->Qtot));
@@ -1270,7 +1315,7 @@ static int sytrd_groups(int64_t n, bool with_q, size_t *lds_bytes)
     // measured sweet spot (tools/eigbench3.py: n = 240 -> 32, n = 510 -> 64 workgroups; flat between 32 and 128)
     int G = n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1));
     while (sytrd_lds(n, G, with_q) > 150 * 1024 && G < 256) G *= 2;
-    const char *env = getenv("JCDF_SYTRD_G");
+    const char *env = diag_env("JCDF_SYTRD_G");
     if (env) {
         const int want = atoi(env);
         if (want >= 1 && want <= 256 && sytrd_lds(n, want, with_q) <= 160 * 1024) G = want;
@@ -1302,7 +1347,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
     // one exchange per column (every workgroup forms the reflector itself) wins while the redundant work is small:
     // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
-    static const int onehop_env = getenv("JCDF_SYTRD_ONEHOP") ? atoi(getenv("JCDF_SYTRD_ONEHOP")) : -1;
+    static const int onehop_env = diag_env("JCDF_SYTRD_ONEHOP") ? atoi(diag_env("JCDF_SYTRD_ONEHOP")) : -1;
     // (with every poll of a thread in flight at once, sub_two_n, the one-exchange kernel also wins at n = 700: 3.86 vs 3.98 ms and
     //  956: 5.86 vs 6.11 ms; at n = 1250 the two-exchange kernel with 512 threads stays ahead: 8.70 vs 8.89 ms)
     const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1000;
@@ -1311,7 +1356,8 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
 #define JCDF_ONEHOP(NR)                                                                                                     \
     do {                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
+        if (hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) \
+            return JCDF_ERR_HIP;                                                                                            \
         hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
                            d_TAU, vg, yg, hg, err, d_Q);                                                                    \
     } while (0)
@@ -1323,7 +1369,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
 #undef JCDF_ONEHOP
         return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
     }
-    (void)hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return JCDF_ERR_HIP;
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
                        hg, err, d_Q);
@@ -1336,6 +1382,7 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
     return jcdf_sytrd_q_device(stream, n, d_A, lda, d_D, d_E, d_TAU, nullptr, d_work, work_bytes);
 }
 
+#ifdef JCDF_DIAGNOSTIC
 int32_t jcdf_sytrd_replay_q_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU, double *d_Q, int64_t ldq)
 {
     if (n <= 0 || n > 640 || !d_A || lda < n || !d_TAU || !d_Q || ldq < n) return JCDF_ERR_INVALID;
@@ -1363,6 +1410,8 @@ int32_t jcdf_keepalive_device(void *stream, int32_t workgroups, int32_t threads,
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
+#endif  // JCDF_DIAGNOSTIC
+
 int64_t jcdf_sytrd_max_n(int32_t with_q)
 {
     int64_t n = 64;
@@ -1370,6 +1419,7 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
     return n;
 }
 
+#ifdef JCDF_DIAGNOSTIC
 // ---- two-stage tridiagonalisation (jcdf_sbr.hpp): dense -> band (16) -> tridiagonal, Q accumulated forwards -------------
 namespace {
 struct Sytrd2Layout {
@@ -1459,7 +1509,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     // Q <- Q (I - V T V^T), panel after panel, needs only the stored V_k, T_k: all of it runs on a side stream of the device
     // BESIDE THE CHASE (one CU, ~1 ms) instead of inside stage 1 (per-panel events cost ~7 us each on the main stream:
     // measured); JCDF_SBR_Q_INLINE=1: right behind each panel's QR on `stream` itself
-    static const bool q_inline = getenv("JCDF_SBR_Q_INLINE") && atoi(getenv("JCDF_SBR_Q_INLINE")) != 0;
+    static const bool q_inline = diag_env("JCDF_SBR_Q_INLINE") && atoi(diag_env("JCDF_SBR_Q_INLINE")) != 0;
     Sytrd2Side *sd = q_inline ? nullptr : sytrd2_side(2);
     if (!q_inline && !sd) return JCDF_ERR_HIP;
     // per panel k: [QR of panel k] -> Y = A22 V -> [A22 update (and, JCDF_SBR_FUSE=1, the QR of panel k+1 in the same launch)]
@@ -1475,7 +1525,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     auto launch_panel = [&](int k) {
         const int m = ni - (k + 1) * SB;
         // JCDF_SBR_PANEL_512=1: 512 threads above 256 rows (two waves per SIMD; measured slower: 256 registers per thread spill)
-        static const bool wide = getenv("JCDF_SBR_PANEL_512") && atoi(getenv("JCDF_SBR_PANEL_512")) != 0;
+        static const bool wide = diag_env("JCDF_SBR_PANEL_512") && atoi(diag_env("JCDF_SBR_PANEL_512")) != 0;
 #define JCDF_PANEL(NR, NT_) hipLaunchKernelGGL((k_sbr_panel<NR, NT_>), dim3(1), dim3(NT_), 0, st, d_A, (int)lda, ni, k, Vb(k), Tb(k))
         if (m <= 256) JCDF_PANEL(1, 256);
         else if (wide && m <= 512) JCDF_PANEL(1, 512);
@@ -1488,7 +1538,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
     };
     // JCDF_SBR_FUSE=1: the QR of panel k+1 as one more block of panel k's update launch (2 launches per panel instead of 3);
     // measured no faster (n = 510: 38-42 us per fused launch against 22 + 14.5 us), so the plain sequence is the default
-    static const bool fuse = getenv("JCDF_SBR_FUSE") && atoi(getenv("JCDF_SBR_FUSE")) != 0;
+    static const bool fuse = diag_env("JCDF_SBR_FUSE") && atoi(diag_env("JCDF_SBR_FUSE")) != 0;
     if (ni - SB >= 2) launch_panel(0);
     for (int k = 0; ni - (k + 1) * SB >= 2; ++k) {
         const int r0 = (k + 1) * SB, m = ni - r0;
@@ -1518,7 +1568,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
         hip_ok = hip_ok && hipEventRecord(sd->events[1], sd->stream) == hipSuccess;
     }
     // two waves per sweep (chain + update) where the ring fits beside the band; JCDF_SB2ST_ONE_WAVE=1: the one-wave kernel
-    static const int variant = getenv("JCDF_SB2ST_VARIANT") ? atoi(getenv("JCDF_SB2ST_VARIANT")) : 1;   // 1: one wave per sweep (fastest measured), 2: chain + update waves, 3: ping-pong
+    static const int variant = diag_env("JCDF_SB2ST_VARIANT") ? atoi(diag_env("JCDF_SB2ST_VARIANT")) : 1;   // 1: one wave per sweep (fastest measured), 2: chain + update waves, 3: ping-pong
     const bool one_wave = variant == 1;
     if (variant == 3 && sb2st3_lds(n) <= 160 * 1024) {
         const size_t lds = sb2st3_lds(n);
@@ -1534,7 +1584,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
                            (int)L.tmax, err);
     } else {
         const size_t lds = sb2st_lds(n);
-        static const int nw = getenv("JCDF_SB2ST_NW") ? atoi(getenv("JCDF_SB2ST_NW")) : SB2ST_WAVES;    // experiments only
+        static const int nw = diag_env("JCDF_SB2ST_NW") ? atoi(diag_env("JCDF_SB2ST_NW")) : SB2ST_WAVES;    // experiments only
 #define JCDF_CHASE1(NW_)                                                                                                         \
     do {                                                                                                                         \
         if (hipFuncSetAttribute((const void *)k_sb2st_chase<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -1553,7 +1603,7 @@ int32_t jcdf_sytrd2_device(void *stream, int64_t n, double *d_A, int64_t lda, do
 }
 
 #ifdef JCDF_SB2ST_PROFILE
-extern "C" int32_t jcdf_sb2st_profile(unsigned long long *out, int32_t reset)       // diagnostic builds only (not in jcdf.h)
+int32_t jcdf_sb2st_profile(unsigned long long *out, int32_t reset)       // diagnostic builds only (not in jcdf.h)
 {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sb2st_prof), sizeof(unsigned long long) * 16 * 8) != hipSuccess) return JCDF_ERR_HIP;
     if (reset) {
@@ -1581,6 +1631,8 @@ int32_t jcdf_sytrd2_apply_q_device(void *stream, int64_t n, double *d_Q, int64_t
                        vlog, (int)L.tmax);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
+
+#endif  // JCDF_DIAGNOSTIC
 
 int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int32_t solve, double *d_Bmat, const double *d_dots,
                          double *d_coef, int32_t *d_flag)
@@ -1707,7 +1759,7 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         const int maxm = lv.maxm;
         const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4;
         if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
-        static const int fuse_max = getenv("JCDF_DC_FUSE_MAX") ? atoi(getenv("JCDF_DC_FUSE_MAX")) : 32;
+        static const int fuse_max = diag_env("JCDF_DC_FUSE_MAX") ? atoi(diag_env("JCDF_DC_FUSE_MAX")) : 32;
         if (maxm <= fuse_max) {       // tiny merges: one launch per level instead of six
             hipLaunchKernelGGL(k_dc_merge_small<4>, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
                                wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc, wk.org, wk.mu, wk.zhat, wk.X, wk.Zp, wk.ldx, wk.G, Zn,
@@ -1810,6 +1862,7 @@ int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, co
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
+#ifdef JCDF_DIAGNOSTIC
 // Diagnostic (JCDF_W_ABLATE=32, C20H42-shaped form only): per-wave cycles of the five segments of the W kernel's phases
 // from the last build: out[(block * waves + wave) * 6 + {issue, mfma, misc, vmcnt wait, barrier, phases}].  Returns the
 // number of wave records written, 0 if the diagnostic build is not active.
@@ -1821,6 +1874,8 @@ int64_t jcdf_w_stall_cycles(jcdf_handle *h, unsigned long long *out, int64_t max
     if (hipMemcpy(out, h->dStall, (size_t)waves * 6 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return waves;
 }
+
+#endif  // JCDF_DIAGNOSTIC
 
 int64_t jcdf_device_bytes(const jcdf_handle *h) { return h ? h->bytes : 0; }
 

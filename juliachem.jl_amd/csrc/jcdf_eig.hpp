@@ -704,6 +704,7 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     }
 }
 
+#ifdef JCDF_DIAGNOSTIC
 // ---- k_sytrd_replay_q: Q = H_0 H_1 ... H_{n-3} from the stored reflectors (LAPACK dorgtr's result, row-major) -----------------
 // Optional (DeviceEigh: JCDF_EIGH_Q_REPLAY=1): Q is not needed by the tridiagonal solver, so instead of accumulating it inside the
 // persistent kernel it can be rebuilt afterwards, row-parallel, on a side stream beside the divide & conquer: row r of Q
@@ -771,6 +772,8 @@ __global__ __launch_bounds__(256) void k_sytrd_replay_q(const double *__restrict
         }
     }
 }
+#endif  // JCDF_DIAGNOSTIC
+
 
 // ---- k_diis_solve: the Pulay step of the SCF wrapper without a round trip to the host ----------------------------
 // (reference: DIIS in src/rhf/energy/EnergyHelpers.jl:234-258 — B matrix of error-vector dot products bordered by

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_trsm_small(const double *__restrict__ L
     }
 }
 
+#ifdef JCDF_DIAGNOSTIC
 // ---- k_keepalive: waves that keep the CUs occupied for a given time (experiment: what the clock governor looks at) ----------
 // After ~1 ms without load on most CUs (the replicated eigensolve: 64 polling workgroups) the next Fock build runs 11-17 %
 // slower at IDENTICAL cycle counts per phase (tools/w_stall.py with W_STALL_GAP_MS): the shader clock has dropped and climbs
@@ -166,5 +167,6 @@ __global__ __launch_bounds__(256) void k_keepalive(unsigned long long ticks, int
     }
     if (x + acc[0] == 123.456) sink[0] = x;                          // keeps the arithmetic alive
 }
+#endif  // JCDF_DIAGNOSTIC
 
 }  // namespace jcdf

@@ -350,6 +350,10 @@ class JCDFHandle:
         else:
             self._check(self._lib.jcdf_set_stream(self._h, stream or None, 0))
 
+    def set_tuning(self, key: str, value: int) -> None:
+        """jcdf_set_tuning: "k_slices_per_xcd", "w_chunk_stages", "host_cholesky" (before configure; 0 = library rule)."""
+        self._check(self._lib.jcdf_set_tuning(self._h, key.encode(), int(value)))
+
     def configure(self, N: int, Q_total: int, q0: int, q1: int, n_occ: int,
                   pq_p: Optional[np.ndarray] = None, pq_q: Optional[np.ndarray] = None) -> None:
         if pq_p is None:

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 
-TWO_STAGE_DEFAULT = False     # flipped once the two-stage path is the faster one on the bench shape
+TWO_STAGE_DEFAULT = False     # the two-stage reduction measured at parity (profiles/r02_two_stage_eigh.txt): diagnostic builds only
 _EVECT_TRIDIAGONAL = 212      # rocblas_evect_tridiagonal
 _SIDE_LEFT = 141              # rocblas_side_left
 _FILL_LOWER = 122             # rocblas_fill_lower
@@ -64,8 +64,10 @@ class DeviceEigh:
             self.own_stedc = not os.environ.get("JCDF_EIGH_VENDOR_STEDC")
             # two-stage reduction (dense -> band -> tridiagonal, csrc/jcdf_sbr.hpp) where the band fits the LDS of one CU;
             # its Q replay runs on a side stream beside the tridiagonal solver.  JCDF_EIGH_TWO_STAGE=0/1 overrides.
+            # (DIAGNOSTIC builds of the library only — the product library does not contain these entry points)
+            diag = hasattr(self.lib, "jcdf_sytrd2_device")
             ts = os.environ.get("JCDF_EIGH_TWO_STAGE")
-            self.two_stage = (self.with_q and self.own_stedc and 3 <= n <= int(self.lib.jcdf_sytrd2_max_n())
+            self.two_stage = (diag and self.with_q and self.own_stedc and 3 <= n <= int(self.lib.jcdf_sytrd2_max_n())
                               and (ts == "1" if ts is not None else TWO_STAGE_DEFAULT))
             if self.two_stage:
                 self.wb2 = int(self.lib.jcdf_sytrd2_workspace_bytes(n))
@@ -73,7 +75,7 @@ class DeviceEigh:
             # JCDF_EIGH_Q_REPLAY=1 (one-stage kernel, n <= 640): Q rebuilt from the stored reflectors on a side stream beside the
             # divide & conquer instead of inside the persistent kernel — measured equal inside the SCF loop (the kernel's hand-off
             # window, not the Q update inside it, sets the time of a column), so the in-kernel accumulation stays the default
-            self.q_replay = (self.with_q and self.own_stedc and not self.two_stage and n <= 640
+            self.q_replay = (diag and self.with_q and self.own_stedc and not self.two_stage and n <= 640
                              and os.environ.get("JCDF_EIGH_Q_REPLAY") == "1")
             if self.two_stage or self.q_replay:
                 self.side = torch.cuda.Stream(device=device)

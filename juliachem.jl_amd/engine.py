@@ -206,7 +206,11 @@ class DeviceSCF:
         keep = s >= 1.0e-6                                          # SCF.jl:142-162
         self.Xp = self._padded((U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T)
         self.E_nuc = E_nuc
-        self.ndiis = ndiis
+        if not 0 <= int(ndiis) <= 15:
+            # the DIIS history lives in device ring buffers and the bordered Pulay system is solved by one workgroup
+            # (jcdf_diis_device: at most 15 vectors); the reference's default is 10 (SCF.jl:364)
+            raise ValueError("ndiis = %r: the device DIIS keeps 0..15 error vectors" % (ndiis,))
+        self.ndiis = int(ndiis)
         self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM
         self.density_solver = (os.environ.get("JCDF_DENSITY_SOLVER") or density_solver or "eigh").lower()
         if self.density_solver not in ("eigh", "sp2"):
@@ -223,7 +227,7 @@ class DeviceSCF:
         self.sp2_reasons = {}
         self.sp2_skip = True                     # first step, and while the density still changes wholesale: eigensolver
         self.canonical = True                    # self.C / self.eps are the eigenvectors / eigenvalues of self.F
-        self.diis_on_host = bool(os.environ.get("JCDF_DIIS_HOST")) or self.ndiis > 15
+        self.diis_on_host = bool(os.environ.get("JCDF_DIIS_HOST"))   # debug: Pulay system solved by numpy (one more sync per iteration)
         # work matrices of the products (padded, zero outside N x N by construction of their factors)
         self.T1 = torch.zeros((self.Np, self.Np), **self._f64)
         self.T2 = torch.zeros((self.Np, self.Np), **self._f64)

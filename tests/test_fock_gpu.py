@@ -18,8 +18,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def _handle(N, Qtot, q0, q1, o, pq=None):
+def _handle(N, Qtot, q0, q1, o, pq=None, tuning=None):
     h = jc.JCDFHandle(0)
+    for k, v in (tuning or {}).items():
+        h.set_tuning(k, v)
     h.configure(N, Qtot, q0, q1, o, *(pq or (None, None)))
     return h
 
@@ -368,34 +370,6 @@ def test_water_golden_energy_trail_on_gpu():
     fb.close()
 
 
-@pytest.mark.parametrize("env", ["JCDF_EIGH_TWO_STAGE", "JCDF_EIGH_Q_REPLAY"])
-def test_water_golden_trail_with_the_optional_eigensolver_paths(env, monkeypatch):
-    """The reference's water / cc-pVDZ SCF trail (golden log) with the two optional forms of the replicated eigensolve — the
-    two-stage reduction, and Q rebuilt from the stored reflectors on a side stream — inside the device SCF loop."""
-    import torch
-    from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
-    from water_case import water
-    monkeypatch.setenv(env, "1")
-    w = water()
-    g = w["golden"]
-    fb = DeviceFockBuilder(25, 96, w["n_occ"], w["aux_shell_nbas"], device=0)
-    fb.set_metric(w["J2c"])
-    fb.set_core_hamiltonian(w["H"])
-    fb.exchange_three_center(torch.as_tensor(np.ascontiguousarray(w["T3"].transpose(2, 1, 0)), device=fb.device).reshape(-1))
-    scf = DeviceSCF(fb, w["H"], w["S"], w["E_nuc"])
-    assert scf.eigh.ok and (scf.eigh.two_stage if env == "JCDF_EIGH_TWO_STAGE" else scf.eigh.q_replay)
-    for it in range(1, 60):
-        E, dE, drms = scf.step()
-        if abs(dE) <= 1e-6 and drms <= 1e-6:
-            break
-    assert it == len(g["trail"]) + 1
-    for (i1, e1, d1, r1), (i2, e2, d2, r2) in zip(scf.trail, g["trail"]):
-        assert i1 == i2 and abs(e1 - e2) < 2e-8 and abs(r1 - r2) < 1e-8, (scf.trail[i1 - 1], g["trail"][i1 - 1])
-    assert abs(E - g["final_energy"]) < 1e-9
-    assert scf.solver_report()["vendor_fallbacks"] == 0
-    fb.close()
-
-
 @pytest.mark.parametrize("n,ormtr", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
                                      (956, 0), (1000, 0), (1001, 0), (1250, 0), (64, 1), (130, 1), (510, 1), (64, 2), (510, 2)])
 def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
@@ -424,93 +398,6 @@ def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     assert np.abs(w - wref).max() < 1e-12 * scale * n
     assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
     assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
-
-
-@pytest.mark.parametrize("n", [3, 4, 5, 17, 18, 19, 33, 34, 64, 100, 130, 257, 510, 590])
-def test_two_stage_tridiagonalisation_matches_numpy(n):
-    """csrc/jcdf_sbr.hpp through the C ABI: dense -> band (16) -> tridiagonal with Q = Q1 Q2 accumulated forwards;
-    A = Q T Q^T, Q orthogonal, spectrum of T = spectrum of A (numpy / LAPACK)."""
-    import ctypes as C
-    import torch
-    lib = jc._lib.load()
-    assert n <= lib.jcdf_sytrd2_max_n()
-    rng = np.random.default_rng(100 + n)
-    A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
-    if n == 64:                                   # degenerate spectrum, zero columns (tau == 0 branches in both stages)
-        A = np.diag(np.repeat(np.arange(8.0), 8)); A[0, 1] = A[1, 0] = 0.5; A[40, 3] = A[3, 40] = -0.25
-    if n == 130:                                  # already banded: stage 1 meets panels that are upper triangular
-        A = np.triu(np.tril(A, 7), -7)
-    dev = torch.device("cuda", 0)
-    f64 = dict(dtype=torch.float64, device=dev)
-    dA = torch.as_tensor(A, device=dev).clone()
-    wb = int(lib.jcdf_sytrd2_workspace_bytes(n))
-    work = torch.zeros(wb // 8 + 8, **f64)
-    D = torch.zeros(n, **f64); E = torch.zeros(n, **f64); Q = torch.zeros((n, n), **f64)
-    p = lambda t: C.c_void_p(t.data_ptr())
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    assert lib.jcdf_sytrd2_device(st, n, p(dA), n, p(D), p(E), p(Q), n, p(work), wb) == 0
-    assert lib.jcdf_sytrd2_apply_q_device(st, n, p(Q), n, p(work), wb) == 0
-    torch.cuda.synchronize()
-    assert int(work[1:2].view(torch.int32)[0].item()) == 0
-    Qh, Dh, Eh = Q.cpu().numpy(), D.cpu().numpy(), E.cpu().numpy()[: n - 1]
-    T = np.diag(Dh) + np.diag(Eh, 1) + np.diag(Eh, -1)
-    scale = max(1.0, np.abs(A).max())
-    assert np.abs(Qh.T @ Qh - np.eye(n)).max() < 1e-13 * n
-    assert np.abs(Qh.T @ A @ Qh - T).max() < 1e-13 * n * scale
-    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A)).max() < 1e-13 * n * scale
-    # argument checks
-    assert lib.jcdf_sytrd2_device(st, int(lib.jcdf_sytrd2_max_n()) + 1, p(dA), n, p(D), p(E), p(Q), n, p(work), wb) != 0
-    assert lib.jcdf_sytrd2_device(st, n, p(dA), n, p(D), p(E), p(Q), n, p(work), wb - 8) != 0
-
-
-@pytest.mark.parametrize("n", [3, 25, 64, 130, 257, 510, 590])
-def test_device_eigh_two_stage_matches_lapack(n, monkeypatch):
-    """DeviceEigh with the two-stage reduction (Q replay on a side stream beside the divide & conquer) vs numpy eigh."""
-    import torch
-    from juliachem_jl_amd.eigh import DeviceEigh
-    monkeypatch.setenv("JCDF_EIGH_TWO_STAGE", "1")
-    rng = np.random.default_rng(n)
-    A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
-    if n == 64:
-        A = np.diag(np.repeat(np.arange(8.0), 8)); A[0, 1] = A[1, 0] = 0.5
-    dev = torch.device("cuda", 0)
-    eg = DeviceEigh(n, dev)
-    assert eg.ok and eg.two_stage, getattr(eg, "reason", "")
-    for rep in range(2):                          # twice: workspace and side-stream state are reusable
-        w, U = eg(torch.as_tensor(A, device=dev))
-        torch.cuda.synchronize()
-        assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")
-        w = w.cpu().numpy().copy(); U = U.cpu().numpy().copy()
-        wref = np.linalg.eigvalsh(A)
-        scale = max(1.0, np.abs(wref).max())
-        assert np.abs(w - wref).max() < 1e-12 * scale * n
-        assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
-        assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
-
-
-@pytest.mark.parametrize("n", [3, 64, 130, 257, 510, 640])
-def test_device_eigh_q_replay_matches_lapack(n, monkeypatch):
-    """DeviceEigh with Q rebuilt from the stored reflectors on a side stream (jcdf_sytrd_replay_q_device) vs numpy eigh."""
-    import torch
-    from juliachem_jl_amd.eigh import DeviceEigh
-    monkeypatch.setenv("JCDF_EIGH_Q_REPLAY", "1")
-    rng = np.random.default_rng(n)
-    A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
-    if n == 64:
-        A = np.diag(np.repeat(np.arange(8.0), 8)); A[0, 1] = A[1, 0] = 0.5
-    dev = torch.device("cuda", 0)
-    eg = DeviceEigh(n, dev)
-    assert eg.ok and eg.q_replay, getattr(eg, "reason", "")
-    for rep in range(2):
-        w, U = eg(torch.as_tensor(A, device=dev))
-        torch.cuda.synchronize()
-        assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")
-        w = w.cpu().numpy().copy(); U = U.cpu().numpy().copy()
-        wref = np.linalg.eigvalsh(A)
-        scale = max(1.0, np.abs(wref).max())
-        assert np.abs(w - wref).max() < 1e-12 * scale * n
-        assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
-        assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
 
 
 def test_operator_with_two_devices_in_one_process(monkeypatch):
@@ -610,16 +497,14 @@ def test_device_potrf_rejects_non_spd():
     assert e.value.code == 5
 
 
-def test_set_metric_device_vs_host_cholesky(monkeypatch):
-    """jcdf_set_metric: device factorisation (default) and the host one (JCDF_HOST_CHOLESKY=1) give the same B."""
+def test_set_metric_device_vs_host_cholesky():
+    """jcdf_set_metric: device factorisation (default) and the host one (jcdf_set_tuning "host_cholesky") give the same B."""
     N, Q, o = 40, 333, 4
     s = synthetic.make(N, Q, o, seed=9)
     T = np.asfortranarray(s.T.reshape(Q, N * N, order="F"))
     out = []
     for host in (False, True):
-        if host:
-            monkeypatch.setenv("JCDF_HOST_CHOLESKY", "1")
-        h = _handle(N, Q, 100, 280, o)                                    # a middle shard
+        h = _handle(N, Q, 100, 280, o, tuning={"host_cholesky": int(host)})     # a middle shard
         h.set_metric(np.tril(s.J2c))
         h.push_three_center(0, Q, T)
         out.append(h.get_B())
@@ -1118,15 +1003,14 @@ def test_scf_tail_record():
 
 
 @pytest.mark.parametrize("m", [1, 3, 8])
-def test_exchange_split_k_is_result_invariant(m, monkeypatch):
-    """The K kernel's split-K slice count (8 x JCDF_K_SLICES_PER_XCD; chosen by jcdf_configure from the tile count)
+def test_exchange_split_k_is_result_invariant(m):
+    """The K kernel's split-K slice count (8 x "k_slices_per_xcd"; chosen by jcdf_configure from the tile count)
     changes the summation tree only: same F to roundoff for any of them, rows beyond the contraction length are zero."""
     N, Q, o = 300, 96, 81
     s = synthetic.make(N, Q, o, seed=13)
     B = orc.calculate_B(s.J2c, s.T)
     ref = s.H + orc.df_rhf_fock_build_BLAS(B, s.C[:, :o])
-    monkeypatch.setenv("JCDF_K_SLICES_PER_XCD", str(m))
-    h = _handle(N, Q, 0, Q, o)
+    h = _handle(N, Q, 0, Q, o, tuning={"k_slices_per_xcd": m})
     h.set_B(np.asfortranarray(B.reshape(Q, N * N, order="F")))
     h.set_core_hamiltonian(s.H)
     F, _ = h.fock_build(s.C[:, :o])

@@ -41,6 +41,22 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().jcdf_abi_version() == 1000
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """The product library exports exactly what include/jcdf.h and include/jcint.h declare (csrc/exports.map): no experiment
+    entry point, no ablation hook, no C++ symbol — and its host code reads no environment variable."""
+    import subprocess
+    if os.path.realpath(_lib.LIB_PATH) != os.path.realpath(os.path.join(ROOT, "juliachem.jl_amd", "lib", "libjcdf_hip.so")):
+        pytest.skip("JCDF_LIB_PATH points at another (diagnostic) build")
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    hdr = open(os.path.join(ROOT, "include", "jcint.h")).read()
+    declared = set(_declared_symbols()) | set(re.findall(r"\b(jcint_[a-z0-9_]+)\s*\(", hdr))
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\bU (secure_)?getenv\b", und), "the product library must not read the environment"
+    assert not _lib.is_diagnostic_build()
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
