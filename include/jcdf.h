@@ -116,6 +116,16 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
  * JCDF_ERR_INVALID for an unknown key or a value out of range. */
 int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value);
 
+/* Exchange screening, the reference's scf flag df_exchange_screen (SCFOptions.jl:92-93; off by default there and here):
+ * calculate_exchange_block_screen_matrix + calculate_K_lower_diagonal_block (ScreenedDF.jl:385-457, 459-545).  K is cut
+ * into n_blocks x n_blocks blocks of width N / n_blocks (N < 100: one block; the reference's df_exchange_n_blocks, CPU
+ * default 10); a block of the lower triangle is computed only if it holds a kept pair of the packed pq map, K = 0 in the
+ * others (what the reference's skipped blocks hold on a fresh Fock array); the ragged strip beyond n_blocks * width is
+ * always computed.  Here: a 64 x 64 block of the K kernel is launched only if it overlaps a kept reference block, and
+ * elements of screened reference blocks are zeroed in the assemble kernel.  n_blocks = 0: off.  Call before
+ * jcdf_configure (it persists across jcdf_configure). */
+int32_t jcdf_set_exchange_screening(jcdf_handle *h, int64_t n_blocks);
+
 /* Metric.  `J2c` = two_center_integrals (Q_total x Q_total column-major, only the
  * lower triangle is read, TwoCenterIntegrals.jl:7-29).  Performs potrf('L') +
  * trtri('L','N') ON THE DEVICE (blocked fp64-MFMA factorisation, csrc/jcdf_chol.hpp —

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "jcdf_set_stream": (C.c_int32, [_P, _P, C.c_int32]),
     "jcdf_configure": (C.c_int32, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "jcdf_set_tuning": (C.c_int32, [_P, C.c_char_p, _I64]),
+    "jcdf_set_exchange_screening": (C.c_int32, [_P, _I64]),
     "jcdf_set_metric": (C.c_int32, [_P, _P]),
     "jcdf_set_metric_inverse": (C.c_int32, [_P, _P]),
     "jcdf_push_three_center": (C.c_int32, [_P, _I64, _I64, _P]),

@@ -71,7 +71,9 @@ struct jcdf_handle {
     bool w_dma = true;                 // LDS-DMA staging (k_exchange_W_dma); false only in diagnostic builds (register-staged k_exchange_W)
     int tq = TILE_Q;                   // aux-index tile of the W kernel: 128, or 256 for the DMA kernel up to 96 orbitals
     int kcw = KCD;                     // slots per stage of the W kernel's stage table (8 resp. 16)
-    int ntri = 0, S = 0, KS = 0;
+    int ngroups = 0, nblk64 = 0, S = 0, KS = 0;      // K kernel: workgroup groups of up to four 64 x 64 blocks, blocks computed, split-K
+    int64_t xs_blocks = 0;                 // jcdf_set_exchange_screening: the reference's df_exchange_n_blocks with df_exchange_screen (0: off)
+    int xs_width = 0, xs_nb = 0;           // K_block_width and block count in effect (ScreenedDF.jl:392-396)
     bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
     bool dense_map = true;
     // jcdf_set_tuning (persist across jcdf_configure); 0 = the library's own rule
@@ -84,6 +86,8 @@ struct jcdf_handle {
     int64_t ldl = 0, linv_rows = 0;
     int *dWchunk = nullptr, *dStgC = nullptr, *dStgQ = nullptr, *dStgP = nullptr;   // stage table of the W kernel
     int *dJrow = nullptr, *dCmap = nullptr;              // packed rows with q >= p; (q,p) -> index into J
+    int *dKgroups = nullptr, *dKblk = nullptr;           // K kernel group descriptors; (bi,bj) -> slab index of the 64 x 64 block
+    unsigned char *dBscr = nullptr;                      // exchange screening: the reference's block_screen_matrix (row-major nb x nb)
     unsigned long long *dStall = nullptr;                // diagnostic builds, JCDF_W_ABLATE=32: per-wave segment cycles of the W kernel
     double *dStage = nullptr;                            // setup staging for pushed three-centre blocks, freed after setup
     int64_t stage_doubles = 0;
@@ -114,7 +118,6 @@ namespace {
     } while (0)
 
 hipError_t ensure_device_attributes();
-constexpr int K_DMA_SMEM_BYTES = 2 * 2 * 128 * KC * 8;      // two buffers x (A block + B block)
 
 int32_t fail(jcdf_handle *h, int32_t code, const std::string &msg)
 {
@@ -163,9 +166,10 @@ void free_all(jcdf_handle *h)
                        &h->dH, &h->dF, &h->dC, &h->dLinv, &h->dStage};
     for (auto b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    int **ibufs[] = {&h->dWchunk, &h->dStgC, &h->dStgQ, &h->dStgP, &h->dJrow, &h->dCmap};
+    int **ibufs[] = {&h->dWchunk, &h->dStgC, &h->dStgQ, &h->dStgP, &h->dJrow, &h->dCmap, &h->dKgroups, &h->dKblk};
     for (auto b : ibufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (h->dBscr) { (void)hipFree(h->dBscr); h->dBscr = nullptr; }
     if (h->dStall) { (void)hipFree(h->dStall); h->dStall = nullptr; }
     for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     h->recs.clear();
@@ -383,19 +387,11 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     };
     auto run_K = [&](size_t slot) {
         KernelRec &r = rec_begin(h, slot, "k_exchange_K", st, ok);
-        const int nblk = (int)(roundup(h->S, 8) * h->ntri);
-#ifdef JCDF_DIAGNOSTIC
-        static const bool k_dma = [] { const char *e = diag_env("JCDF_K_DMA"); return !(e && atoi(e) == 0); }();
-        if (!k_dma)
-            hipLaunchKernelGGL(k_exchange_K<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), GemmNT<KCfg4>::SMEM_BYTES, st, h->dWt,
-                               h->Wld, h->ntri, h->S, h->KS, h->dKslab);
-        else
-#endif
-            hipLaunchKernelGGL(k_exchange_K_dma<KCfg4>, dim3((unsigned)nblk), dim3(KCfg4::NT), K_DMA_SMEM_BYTES, st, h->dWt, h->Wld,
-                               h->ntri, h->S, h->KS, h->dKslab);
-        const double nT = (double)(h->Np / TILE_P);
-        // diagonal tiles: the wave that owns the upper 64 x 64 block issues no MFMA
-        r.flops = 2.0 * ((double)h->ntri - 0.25 * nT) * 128.0 * 128.0 * (double)h->S * (double)h->KS;
+        const int nwg = (int)(roundup(h->S, 8) * h->ngroups);
+        hipLaunchKernelGGL(k_exchange_K64, dim3((unsigned)nwg), dim3(256), K64_SMEM_BYTES, st, h->dWt, h->Wld, h->dKgroups, h->ngroups,
+                           h->S, h->KS, h->dKslab, h->nblk64);
+        // one wave per needed 64 x 64 block of the lower triangle (diagonal blocks are computed whole)
+        r.flops = 2.0 * (double)h->nblk64 * 64.0 * 64.0 * (double)h->S * (double)h->KS;
         r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
         r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
         ok(hipEventRecord(r.e1, st));
@@ -421,7 +417,8 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     {
         KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st, ok);
         hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
-                           st, h->dJ, h->dCmap, h->dKslab, h->S, h->ntri, h->have_H ? h->dH : nullptr, (int)h->N, dF);
+                           st, h->dJ, h->dCmap, h->dKslab, h->S, h->nblk64, h->dKblk, h->dBscr, h->xs_width, h->xs_nb,
+                           h->have_H ? h->dH : nullptr, (int)h->N, dF);
         r.alg_bytes = 8.0 * N * N * (h->have_H ? 2.0 : 1.0);
         ok(hipEventRecord(r.e1, st));
     }
@@ -711,10 +708,7 @@ hipError_t set_device_kernel_attributes()
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (first == hipSuccess && e != hipSuccess) first = e;
     };
-#ifdef JCDF_DIAGNOSTIC
-    set((const void *)k_exchange_K<KCfg4>, GemmNT<KCfg4>::SMEM_BYTES);
-#endif
-    set((const void *)k_exchange_K_dma<KCfg4>, K_DMA_SMEM_BYTES);
+    set((const void *)k_exchange_K64, K64_SMEM_BYTES);
     set((const void *)k_metric_apply, GemmNT<MCfg>::SMEM_BYTES);
     set((const void *)k_coulomb_J, 150 * 1024);
     set((const void *)k_chol_diag, CHOL_DIAG_LDS);
@@ -843,6 +837,14 @@ int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value)
     } else {
         return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: unknown key '" + k + "'");
     }
+    return JCDF_OK;
+}
+
+int32_t jcdf_set_exchange_screening(jcdf_handle *h, int64_t n_blocks)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (n_blocks < 0 || n_blocks > 4096) return fail(h, JCDF_ERR_INVALID, "jcdf_set_exchange_screening: n_blocks in 0..4096");
+    h->xs_blocks = n_blocks;
     return JCDF_OK;
 }
 
@@ -992,13 +994,106 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     h->n_chunks = (int)wchunk.size() - 1;
     h->Plow = (int64_t)jrow.size();
 
-    // K: lower block-triangle of 128x128 tiles, split-K so that one wave of workgroups fills the chip
-    const int nT = (int)(h->Np / TILE_P);
-    h->ntri = nT * (nT + 1) / 2;
+    // ---- K kernel: the needed 64 x 64 blocks of the lower triangle, packed four to a workgroup ------------------------
+    // Exchange screening (jcdf_set_exchange_screening; calculate_exchange_block_screen_matrix, ScreenedDF.jl:385-457): the
+    // reference's K blocks of width N / n_blocks (one block below N = 100); a block is kept when it holds a kept pair; the
+    // ragged strip q >= n_blocks * width is always computed (ScreenedDF.jl:518-545).
+    std::vector<int> kgroups, kblk;
+    std::vector<unsigned char> bscr;
+    h->xs_nb = h->xs_width = 0;
+    try {
+        const int Nb = (int)((N + 63) / 64);
+        if (h->xs_blocks > 0) {
+            h->xs_nb = N < 100 ? 1 : (int)std::min<int64_t>(h->xs_blocks, N);
+            h->xs_width = N < 100 ? (int)N : (int)(N / h->xs_nb);
+            bscr.assign((size_t)h->xs_nb * h->xs_nb, 0);
+            for (int64_t c = 0; c < P; ++c) {
+                const int64_t p = pq_p ? pq_p[c] : c / N, q = pq_q ? pq_q[c] : c % N;
+                if (q < p) continue;
+                const int64_t bq = q / h->xs_width, bp = p / h->xs_width;
+                if (bq < h->xs_nb && bp < h->xs_nb) bscr[(size_t)(bq * h->xs_nb + bp)] = 1;
+            }
+        }
+        auto needed = [&](int bi, int bj) {                  // does block (bi >= bj) hold an element whose K is kept?
+            if (bscr.empty()) return true;
+            const int q0 = bi * 64, q1 = std::min<int>((int)N, q0 + 64) - 1, p0 = bj * 64, p1 = std::min<int>((int)N, p0 + 64) - 1;
+            if (q1 >= h->xs_nb * h->xs_width) return true;   // reaches into the strip
+            for (int bq = q0 / h->xs_width; bq <= q1 / h->xs_width; ++bq)
+                for (int bp = p0 / h->xs_width; bp <= std::min(p1 / h->xs_width, bq); ++bp)
+                    if (bscr[(size_t)bq * h->xs_nb + bp]) return true;
+            return false;
+        };
+        kblk.assign((size_t)Nb * (Nb + 1) / 2, -1);
+        int nblk = 0;
+        // a group: up to 4 blocks over at most 4 distinct row blocks
+        std::vector<int> rows, blocks;                       // pending group: row blocks, (bi, bj) pairs
+        auto flush = [&]() {
+            if (blocks.empty()) return;
+            int d[16];
+            for (int k = 0; k < 4; ++k) d[k] = k < (int)rows.size() ? rows[k] : -1;
+            for (int w = 0; w < 4; ++w) {
+                if (2 * w < (int)blocks.size()) {
+                    const int bi = blocks[2 * w], bj = blocks[2 * w + 1];
+                    d[4 + 3 * w] = (int)(std::find(rows.begin(), rows.end(), bi) - rows.begin());
+                    d[5 + 3 * w] = (int)(std::find(rows.begin(), rows.end(), bj) - rows.begin());
+                    d[6 + 3 * w] = kblk[(size_t)bi * (bi + 1) / 2 + bj];
+                } else {
+                    d[4 + 3 * w] = d[5 + 3 * w] = 0;
+                    d[6 + 3 * w] = -1;
+                }
+            }
+            kgroups.insert(kgroups.end(), d, d + 16);
+            rows.clear();
+            blocks.clear();
+        };
+        auto add = [&](int bi, int bj) {
+            std::vector<int> nr = rows;
+            if (std::find(nr.begin(), nr.end(), bi) == nr.end()) nr.push_back(bi);
+            if (std::find(nr.begin(), nr.end(), bj) == nr.end()) nr.push_back(bj);
+            if (blocks.size() >= 8 || nr.size() > 4) {
+                flush();
+                nr.clear();
+                nr.push_back(bi);
+                if (bj != bi) nr.push_back(bj);
+            }
+            rows = nr;
+            kblk[(size_t)bi * (bi + 1) / 2 + bj] = nblk++;
+            blocks.push_back(bi);
+            blocks.push_back(bj);
+        };
+        const int nT = (Nb + 1) / 2;
+        std::vector<std::pair<int, int>> part;               // blocks of 128-tiles that are not a full 2 x 2 group
+        for (int ti = 0; ti < nT; ++ti)
+            for (int tj = 0; tj <= ti; ++tj) {
+                std::vector<std::pair<int, int>> tb;
+                for (int a = 0; a < 2; ++a)
+                    for (int c = 0; c < 2; ++c) {
+                        const int bi = 2 * ti + a, bj = 2 * tj + c;
+                        if (bi < Nb && bj <= bi && needed(bi, bj)) tb.push_back({bi, bj});
+                    }
+                if (tb.size() == 4) {                        // full off-diagonal tile: its own group
+                    flush();
+                    for (auto &x : tb) add(x.first, x.second);
+                    flush();
+                } else {
+                    part.insert(part.end(), tb.begin(), tb.end());
+                }
+            }
+        // the partial tiles (diagonal ones, screened ones, the half tile of an odd block count) in row-major block order:
+        // neighbours share row blocks
+        std::sort(part.begin(), part.end());
+        for (auto &x : part) add(x.first, x.second);
+        flush();
+        h->nblk64 = nblk;
+        h->ngroups = (int)(kgroups.size() / 16);
+        if (h->ngroups == 0) return fail(h, JCDF_ERR_INVALID, "jcdf_configure: exchange screening left no K block (empty pair list?)");
+    } catch (...) {
+        return fail(h, JCDF_ERR_ALLOC, "jcdf_configure: out of host memory for the K block list");
+    }
     const int64_t Ktot = h->o * h->ldq;
     // Split-K: all tiles of one k-slice run on one XCD (they share W rows through that L2), so the slice count is a
     // multiple of 8: m slices per XCD.  Measured (tools/prof_fock.py, JCDF_K_SLICES_PER_XCD): when the lower triangle has
-    // at most one tile per CU of an XCD, the best m is the largest for which all ntri * m workgroups are resident at once
+    // at most one tile per CU of an XCD, the best m is the largest for which all ngroups * m workgroups are resident at once
     // (2 per CU; N = 510: m = 6 0.91 ms, m = 8 1.18, m = 16 1.18 — a partial second round costs more than it balances);
     // with more tiles than that a single round leaves some CUs with two workgroups and the rest with one (N = 956:
     // m = 1 9.2 ms), and many short rounds balance better (m = 8 6.7 ms; N = 1250: 19.9 -> 18.3 ms).  Model: busiest
@@ -1009,15 +1104,15 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     static const double K_MULTI_ROUND_CHARGE = [] { const char *e = diag_env("JCDF_K_MULTI_CHARGE"); return e ? atof(e) : 1.0; }();
     const int64_t cus_per_xcd = std::max(1, h->num_cu / 8);
     const int64_t slots_per_xcd = 2 * cus_per_xcd;
-    int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ntri);
+    int64_t per_xcd = std::max<int64_t>(1, slots_per_xcd / h->ngroups);
     {
-        const int64_t w1 = h->ntri * per_xcd;                              // single round
+        const int64_t w1 = h->ngroups * per_xcd;                              // single round
         const double single = (double)((w1 + cus_per_xcd - 1) / cus_per_xcd) / (double)per_xcd;
         double best = 1e300;
         int64_t best_m = 0;
-        for (int64_t m = 4; m <= 12 && h->ntri > cus_per_xcd; ++m) {
-            if (h->ntri * m <= slots_per_xcd || 8 * m > max_chunks || 8 * m * h->ntri * 128 * 128 * 8 > (int64_t)512 << 20) continue;
-            const double cost = K_MULTI_ROUND_CHARGE * (double)((h->ntri * m + cus_per_xcd - 1) / cus_per_xcd) / (double)m;
+        for (int64_t m = 4; m <= 12 && h->ngroups > cus_per_xcd; ++m) {
+            if (h->ngroups * m <= slots_per_xcd || 8 * m > max_chunks || 8 * m * (int64_t)h->nblk64 * 64 * 64 * 8 > (int64_t)512 << 20) continue;
+            const double cost = K_MULTI_ROUND_CHARGE * (double)((h->ngroups * m + cus_per_xcd - 1) / cus_per_xcd) / (double)m;
             if (cost <= best) { best = cost; best_m = m; }                 // ties: the finer split
         }
         if (best_m && best < 0.99 * single) per_xcd = best_m;
@@ -1038,7 +1133,7 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     if ((rc = dev_alloc(h, &h->dVpart, (int64_t)h->n_chunks * h->n_mtiles * h->vld, true))) return rc;
     if ((rc = dev_alloc(h, &h->dV, h->ldq, true))) return rc;
     if ((rc = dev_alloc(h, &h->dJ, h->Plow, true))) return rc;
-    if ((rc = dev_alloc(h, &h->dKslab, (int64_t)h->S * h->ntri * 128 * 128, true))) return rc;
+    if ((rc = dev_alloc(h, &h->dKslab, (int64_t)h->S * h->nblk64 * 64 * 64, true))) return rc;
     if ((rc = dev_alloc(h, &h->dH, N * N, true))) return rc;
     if ((rc = dev_alloc(h, &h->dF, N * N, true))) return rc;
     if ((rc = dev_alloc(h, &h->dC, N * n_occ, true))) return rc;
@@ -1048,6 +1143,9 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
     if ((rc = dev_upload(h, &h->dStgP, stg_p))) return rc;
     if ((rc = dev_upload(h, &h->dJrow, jrow))) return rc;
     if ((rc = dev_upload(h, &h->dCmap, cmap))) return rc;
+    if ((rc = dev_upload(h, &h->dKgroups, kgroups))) return rc;
+    if ((rc = dev_upload(h, &h->dKblk, kblk))) return rc;
+    if (!bscr.empty() && (rc = dev_upload(h, &h->dBscr, bscr))) return rc;
     if (h->w_ablate == 32 && (rc = dev_alloc(h, &h->dStall, (int64_t)h->n_chunks * h->n_mtiles * h->n_qt * 8 * 6, true))) return rc;
     JCDF_HIP(h, hipStreamSynchronize(h->stream));       // the host vectors above go out of scope
     h->configured = true;

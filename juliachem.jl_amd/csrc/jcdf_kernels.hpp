@@ -470,42 +470,51 @@ __global__ __launch_bounds__(256, JCDF_J_BLOCKS_PER_CU) void k_coulomb_J(
 }
 
 // ---------------------------------------------------------------------------
-// k_exchange_K: Kslab[s][t] = sum_{k in slice s} Wt[ti-tile][k] Wt[tj-tile][k]
-// for lower block-triangle tiles t = (ti >= tj), k = (i, Q).  SYRK with a huge contraction
-// (o*ldq) and a tiny output -> split-K over slices, deterministic slab reduce in
-// k_fock_assemble.  Reference: calcululate_K_no_sym_GPU! / lower-triangle block
-// GEMMs (GPUDF.jl:669-672, 758-826) / DenseGPUDF.jl:111.
+// k_exchange_K64: Kslab[s][blk] = sum_{k in slice s} W[row-block bi][k] W[row-block bj][k] for the 64 x 64 blocks
+// (bi >= bj) of the lower triangle that are needed, k = (i, Q).  SYRK with a huge contraction (o*ldq) and a tiny output
+// -> split-K over slices, deterministic slab reduce in k_fock_assemble.  Reference: calcululate_K_no_sym_GPU! /
+// lower-triangle block GEMMs (GPUDF.jl:669-672, 758-826) / DenseGPUDF.jl:111; with exchange screening the block list
+// of calculate_exchange_block_screen_matrix + calculate_K_lower_diagonal_block (ScreenedDF.jl:431-447, 459-545).
+//
+// Unit of work = one WAVE computing one 64 x 64 block (16 MFMA tiles, 128 accumulator registers).  A workgroup is a
+// GROUP of up to four such blocks that together touch at most four 64-row blocks of W (jcdf_configure builds the
+// groups: an off-diagonal 128 x 128 tile is one group of 2 x 2 blocks sharing 2 + 2 row blocks; the 3-block diagonal
+// 128-tiles are packed four blocks to a group across neighbouring tiles, so no wave idles and no upper-triangle
+// block is computed: N = 510 -> 36 blocks in 9 groups where 128-tiles needed 10 workgroups with 4 idle waves).
+// Staging: one stage = 16 k of the group's four row blocks = 4 x 8 KB, each a CONTIGUOUS 8 KB half of a 16 KB block
+// of Wb, copied by LDS-DMA (global_load_lds_dwordx4, 8 wave instructions of 1 KB per row block, wave w moves row
+// block w) with the 16-B chunks of every row XOR-swizzled ON THE SOURCE SIDE (the DMA's LDS side is lane-linear):
+// chunk c of row r lands at chunk position c ^ ((r >> 1) & 7).  Rows are 128 B = half a bank row, so the 16 rows one
+// 32-lane half of a ds_read_b64 touches (same k chunk) fall on 2 x 8 distinct 16-B slots: conflict-free (the earlier
+// key r & 7 left rows r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+// Two LDS buffers: the DMA of stage t+1 is issued at the start of phase t into the buffer phase t-1 has finished
+// reading and has the whole phase (64 MFMAs per wave) to land; operands come from L2 (all groups of a k-slice run on
+// one XCD).  No staging registers, no ds_write.
+// Group descriptor (16 ints): rb[4] = staged row blocks (-1: slot unused), then per wave {slot a, slot b, output
+// block index or -1 (idle wave)}.
 // ---------------------------------------------------------------------------
-using KCfg4 = GemmCfg<4, 4, 2, 2, KC>;   // 128 x 128 tile, 4 waves of 64 x 64
-// The same SYRK with LDS-DMA staging: an operand stage IS one contiguous 16 KB block of Wb, so 16 wave instructions of
-// 1 KB copy it into LDS — with the 16-B chunks of every row XOR-swizzled by the low row bits ON THE SOURCE SIDE (the
-// DMA's LDS side is lane-linear): chunk c of row r lands at chunk position c ^ (r & 7).  (A plain copy makes the 16
-// rows of an operand read hit two banks, 8-way conflicts: 35 instead of 60 TF.)  What is left is the 2-way conflict
-// of rows r and r + 8, 16 LDS cycles per k step against 1024 MFMA cycles.  Two LDS buffers: the DMA of stage t+1 is issued at the start of
-// phase t into the buffer phase t-1 has finished reading and has the whole phase (64 MFMAs per wave) to land; operands
-// come from L2.  No staging registers, no ds_write, no address arithmetic in the loop beyond one pointer increment.
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT, 2) void k_exchange_K_dma(const double *__restrict__ Wt, int64_t Wld, int ntri, int S, int KS,
-                                                               double *__restrict__ Kslab)
+constexpr int KB64 = 64;                          // block edge
+constexpr int K64_STAGE = 4 * KB64 * KC;          // doubles per stage (4 row blocks x 64 rows x 16 k)
+constexpr int K64_SMEM_BYTES = 2 * K64_STAGE * 8; // two buffers
+
+__global__ __launch_bounds__(256, 2) void k_exchange_K64(const double *__restrict__ Wt, int64_t Wld, const int *__restrict__ groups,
+                                                         int ngroups, int S, int KS, double *__restrict__ Kslab, int nblk64)
 {
-    static_assert(Cfg::TM == 128 && Cfg::TN == 128 && Cfg::KC == 16 && Cfg::NT == 256, "written for 128 x 128 x 16 stages, 4 waves");
-    constexpr int WM = Cfg::WM, WN = Cfg::WN, BLK = 128 * KC;        // doubles per operand block
+    constexpr int WM = 4, WN = 4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     const int xcd = b & 7, r = b >> 3;
-    const int t = r % ntri;
-    const int s = (r / ntri) * 8 + xcd;
+    const int g = r % ngroups;
+    const int s = (r / ngroups) * 8 + xcd;
     if (s >= S) return;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const bool same = ti == tj;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     const int lr = lane & 15, lk = lane >> 4;
-    const bool mfma_on = !(same && wave == 1);                        // upper 64 x 64 block of a diagonal tile
+    const int *G = groups + 16 * g;
+    const int my_rb = G[wave];                                        // row block this wave stages (-1: none)
+    const int pa = G[4 + 3 * wave], pb = G[5 + 3 * wave], ob = G[6 + 3 * wave];
+    const bool mfma_on = ob >= 0;
 
     double4_t acc[WM][WN];
 #pragma unroll
@@ -515,32 +524,32 @@ __global__ __launch_bounds__(Cfg::NT, 2) void k_exchange_K_dma(const double *__r
 
     const int64_t nkb = Wld / KC;
     const int nchunks = KS / KC;
-    // lane l of a piece fills LDS row l/8, chunk position l%8 of the piece's 8 rows from global chunk (l%8) ^ (l/8)
-    const int lsrc = (lane >> 3) * KC + (((lane & 7) ^ (lane >> 3)) << 1);
-    const double *Ab = Wt + ((int64_t)ti * nkb + (int64_t)s * nchunks) * BLK + wave * 4 * 128 + lsrc;
-    const double *Bb = Wt + ((int64_t)tj * nkb + (int64_t)s * nchunks) * BLK + wave * 4 * 128 + lsrc;
+    // piece i (8 rows) of this wave's row block: lane l fills LDS row 8 i + l/8, chunk position l%8, from source chunk
+    // (l%8) ^ key(row), key(row) = (row >> 1) & 7 = (4 i + (l >> 4)) & 7: l >> 4 for even i, 4 + (l >> 4) for odd i
+    const int lrow = (lane >> 3) * KC;
+    const int src_even = lrow + (((lane & 7) ^ (lane >> 4)) << 1);
+    const int src_odd = lrow + (((lane & 7) ^ (4 + (lane >> 4))) << 1);
+    const int rbs = my_rb < 0 ? 0 : my_rb;
+    const double *Sb = Wt + (((int64_t)(rbs >> 1) * nkb + (int64_t)s * nchunks) * 128 + (rbs & 1) * 64) * KC;
     auto issue = [&](int buf, int chunk) {
-        double *As = smem + buf * (2 * BLK) + wave * 4 * 128;
+        if (my_rb < 0) return;                                        // wave-uniform
+        double *Ls = smem + buf * K64_STAGE + wave * (KB64 * KC);
+        const double *src = Sb + (int64_t)chunk * (128 * KC);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(Ab + (int64_t)chunk * BLK + i * 128), (lds_void_t *)(As + i * 128), 16, 0, 0);
-        if (!same) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(Bb + (int64_t)chunk * BLK + i * 128), (lds_void_t *)(As + BLK + i * 128), 16,
-                                                 0, 0);
-        }
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(src + i * 128 + ((i & 1) ? src_odd : src_even)), (lds_void_t *)(Ls + i * 128), 16, 0,
+                                             0);
     };
-    int koff[KC / 4];                                 // position of k = 4 ks + lk in this lane's rows (row & 7 == lr & 7)
+    int koff[KC / 4];                                 // position of k = 4 ks + lk in this lane's rows (key = lr >> 1 for every m)
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
         const int k = 4 * ks + lk;
-        koff[ks] = (((k >> 1) ^ (lr & 7)) << 1) | (k & 1);
+        koff[ks] = (((k >> 1) ^ (lr >> 1)) << 1) | (k & 1);
     }
     auto compute_stage = [&](int buf) {
         if (!mfma_on) return;
-        const double *As = smem + buf * (2 * BLK) + (wm * (WM * 16) + lr) * KC;
-        const double *Bs = smem + buf * (2 * BLK) + (same ? 0 : BLK) + (wn * (WN * 16) + lr) * KC;
+        const double *As = smem + buf * K64_STAGE + pa * (KB64 * KC) + lr * KC;
+        const double *Bs = smem + buf * K64_STAGE + pb * (KB64 * KC) + lr * KC;
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             double a[WM], bb[WN];
@@ -565,14 +574,14 @@ __global__ __launch_bounds__(Cfg::NT, 2) void k_exchange_K_dma(const double *__r
         __builtin_amdgcn_s_barrier();
     }
 
-    double *out = Kslab + ((int64_t)s * ntri + t) * (Cfg::TM * Cfg::TN);
     if (mfma_on) {
+        double *out = Kslab + ((int64_t)s * nblk64 + ob) * (KB64 * KB64);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int n = 0; n < WN; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[tile_row<Cfg>(m, j) * Cfg::TN + tile_col<Cfg>(n)] = acc[m][n][j];
+                for (int j = 0; j < 4; ++j) out[(m * 16 + lk + 4 * j) * KB64 + n * 16 + lr] = acc[m][n][j];
     }
 }
 
@@ -582,9 +591,14 @@ __global__ __launch_bounds__(Cfg::NT, 2) void k_exchange_K_dma(const double *__r
 // packed lower pairs through cmap[q + N p] (index into J, -1: screened pair).
 // Replaces copy_screened_J_to_fock_upper_triangle + copy_upper_to_lower_kernel
 // + axpy!(H) (GPUDF.jl:482-536, 221-225).
+// kblk[bi (bi+1)/2 + bj] = slab index of the 64 x 64 block (bi >= bj), -1: block not computed.  Exchange screening
+// (bscr != NULL; ScreenedDF.jl:431-447): element (q, p), q >= p, takes its K only if the reference's K block
+// (q / bsw, p / bsw) is kept or q lies in the ragged strip q >= nbs * bsw the reference always computes
+// (ScreenedDF.jl:518-545); elsewhere K = 0, which is what the reference's skipped blocks hold on a fresh Fock array.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fock_assemble(
-    const double *__restrict__ J, const int *__restrict__ cmap, const double *__restrict__ Kslab, int S, int ntri,
+    const double *__restrict__ J, const int *__restrict__ cmap, const double *__restrict__ Kslab, int S, int nblk64,
+    const int *__restrict__ kblk, const unsigned char *__restrict__ bscr, int bsw, int nbs,
     const double *__restrict__ H, int N, double *__restrict__ F)
 {
     const int q = blockIdx.y;
@@ -592,11 +606,15 @@ __global__ __launch_bounds__(256) void k_fock_assemble(
     if (p > q || q >= N) return;
     const int jc = cmap[q + (int64_t)N * p];
     const double j = jc >= 0 ? J[jc] : 0.0;
-    const int ti = q >> 7, tj = p >> 7;
-    const int t = ti * (ti + 1) / 2 + tj;
-    const int64_t off = (int64_t)t * (128 * 128) + (q & 127) * 128 + (p & 127);
+    const int bi = q >> 6, bj = p >> 6;
+    const int blk = kblk[bi * (bi + 1) / 2 + bj];
+    bool kept = blk >= 0;
+    if (bscr && kept) kept = q >= nbs * bsw || bscr[(q / bsw) * nbs + p / bsw] != 0;
     double k = 0.0;
-    for (int s = 0; s < S; ++s) k += Kslab[(int64_t)s * ntri * (128 * 128) + off];
+    if (kept) {
+        const int64_t off = (int64_t)blk * (KB64 * KB64) + (q & 63) * KB64 + (p & 63);
+        for (int s = 0; s < S; ++s) k += Kslab[(int64_t)s * nblk64 * (KB64 * KB64) + off];
+    }
     const double v = 2.0 * j - k;
     const int64_t lo = q + (int64_t)N * p, up = p + (int64_t)N * q;
     F[lo] = v + (H ? H[lo] : 0.0);

@@ -1,5 +1,6 @@
-// jcdf_kernels_diag.hpp - the register-staged predecessors of k_exchange_W_dma / k_exchange_K_dma.  NOT part of the
-// shipping library: compiled only with -DJCDF_DIAGNOSTIC (tools/build_diag.sh) for A/B timing against the LDS-DMA forms.
+// jcdf_kernels_diag.hpp - the register-staged predecessor of k_exchange_W_dma.  NOT part of the
+// shipping library: compiled only with -DJCDF_DIAGNOSTIC (tools/build_diag.sh) for A/B timing against the LDS-DMA form
+// (the round-1/2 K kernels on 128 x 128 tiles are in the git history: their slab layout differs from k_exchange_K64's).
 #pragma once
 #include "jcdf_kernels.hpp"
 
@@ -213,45 +214,5 @@ __global__ __launch_bounds__(256 * WVM, (WVM == 1 && WM <= 6) ? 2 : ((WVM == 2) 
         vp[16] = vacc[1];
     }
 }
-
-
-
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT, (Cfg::NT == 256) ? 2 : 1) void k_exchange_K(
-    const double *__restrict__ Wt, int64_t Wld, int ntri, int S, int KS, double *__restrict__ Kslab)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    // all tiles of one k-slice on one XCD: they re-read the same W columns through that L2
-    const int b = blockIdx.x;
-    const int xcd = b & 7, r = b >> 3;
-    const int t = r % ntri;
-    const int s = (r / ntri) * 8 + xcd;
-    if (s >= S) return;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-
-    double4_t acc[Cfg::WM][Cfg::WN];
-#pragma unroll
-    for (int m = 0; m < Cfg::WM; ++m)
-#pragma unroll
-        for (int n = 0; n < Cfg::WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
-
-    // operand stage = one contiguous 16 KB block of Wb: "row stride" 16, chunk stride 128*16 doubles
-    const int64_t nkb = Wld / KC;
-    const double *base = Wt + (int64_t)s * (KS / KC) * (128 * KC);
-    gemm_nt_core<Cfg, false, true>(base + (int64_t)ti * nkb * (128 * KC), KC, base + (int64_t)tj * nkb * (128 * KC), KC, KS / KC,
-                                   acc, smem, ti == tj, !(ti == tj && (int)(threadIdx.x >> 6) == 1));
-
-    double *out = Kslab + ((int64_t)s * ntri + t) * (Cfg::TM * Cfg::TN);
-#pragma unroll
-    for (int m = 0; m < Cfg::WM; ++m)
-#pragma unroll
-        for (int n = 0; n < Cfg::WN; ++n)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                out[tile_row<Cfg>(m, j) * Cfg::TN + tile_col<Cfg>(n)] = acc[m][n][j];
-}
-
 
 }  // namespace jcdf

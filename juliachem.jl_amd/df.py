@@ -117,6 +117,21 @@ class SCFOptions:
     df_K_sym_type: str = "square"
 
 
+DF_EXCHANGE_N_BLOCKS_CPU_DEFAULT = 10      # Constants.jl:13 — the mode of the reference that screens exchange blocks
+
+
+def exchange_screen_blocks(scf_options: "SCFOptions") -> int:
+    """n_blocks for jcdf_set_exchange_screening: 0 unless df_exchange_screen is set (SCFOptions.jl:92-93); then the
+    user's df_exchange_n_blocks or the default of the reference's screened mode (ScreenedDF.jl:120-122, 385-389).
+    The other exchange knobs of the reference's GPU path — df_use_K_sym, df_K_sym_type (square / rect forms of the same
+    lower-triangle K, GPUDF.jl:35,669-826) and, without df_exchange_screen, df_exchange_n_blocks (block width of its
+    cuBLAS calls, GPUDF.jl:61-72) — select among algorithms with identical results; this library has one K kernel
+    (64 x 64 blocks of the lower triangle, split-K chosen by jcdf_configure), so they are accepted and have no effect."""
+    if not scf_options.df_screen_exchange:
+        return 0
+    return int(scf_options.df_exchange_n_blocks) or DF_EXCHANGE_N_BLOCKS_CPU_DEFAULT
+
+
 def create_scf_options(scf_flags: Dict[str, Any]) -> SCFOptions:
     """JSON keywords.scf -> SCFOptions with the reference's defaults and its
     df_* aliasing rules (SCFOptions.jl:47-139, Constants.jl:3-78)."""
@@ -353,6 +368,11 @@ class JCDFHandle:
     def set_tuning(self, key: str, value: int) -> None:
         """jcdf_set_tuning: "k_slices_per_xcd", "w_chunk_stages", "host_cholesky" (before configure; 0 = library rule)."""
         self._check(self._lib.jcdf_set_tuning(self._h, key.encode(), int(value)))
+
+    def set_exchange_screening(self, n_blocks: int) -> None:
+        """df_exchange_screen of the reference (ScreenedDF.jl:431-447, 459-545): K blocks of width N / n_blocks without a
+        kept pair are not computed (K = 0 there).  Before configure; 0 = off."""
+        self._check(self._lib.jcdf_set_exchange_screening(self._h, int(n_blocks)))
 
     def configure(self, N: int, Q_total: int, q0: int, q1: int, n_occ: int,
                   pq_p: Optional[np.ndarray] = None, pq_q: Optional[np.ndarray] = None) -> None:
@@ -658,6 +678,7 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
             if len(rows) == 0:
                 raise JCDFError(1, "more devices than auxiliary shells: empty shard")
             h = JCDFHandle(_physical_device(dev if n_ranks == 1 else _local_device(dev, num_devices)))
+            h.set_exchange_screening(exchange_screen_blocks(scf_options))
             h.configure(n, scf_data.A, rows.start, rows.stop, n_occ, pq[0], pq[1])
             h.set_core_hamiltonian(H if (rank == 0 and dev == 0) else None)   # GPUDF.jl:158-161
             gd.handles.append(h)

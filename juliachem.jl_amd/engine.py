@@ -100,7 +100,8 @@ class DeviceFockBuilder:
     """F = H + sum_shards (2 J_s - K_s) with this rank's shard on this rank's GPU."""
 
     def __init__(self, N: int, Q_total: int, n_occ: int, aux_shell_nbas: Sequence[int],
-                 device: Optional[int] = None, pq: Tuple[Optional[np.ndarray], Optional[np.ndarray]] = (None, None)):
+                 device: Optional[int] = None, pq: Tuple[Optional[np.ndarray], Optional[np.ndarray]] = (None, None),
+                 exchange_screen_blocks: int = 0):
         self.rank, self.world, self.dist = _dist()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,6 +116,7 @@ class DeviceFockBuilder:
         # every library operation goes on torch's current stream: ordered with the torch ops
         # that produce its inputs (C_occ, the T blocks) and consume its output (F)
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.h.set_exchange_screening(exchange_screen_blocks)      # df_exchange_screen (ScreenedDF.jl:431-447); 0 = off
         self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
         self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
         self.time_collectives = False      # bench: device events around the broadcast of C and the all-reduce of F

@@ -12,7 +12,7 @@ from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .df import (JCTC, create_jctiming, create_scf_options, get_screening_metadata, packed_pq_lists)
+from .df import (JCTC, create_jctiming, create_scf_options, exchange_screen_blocks, get_screening_metadata, packed_pq_lists)
 from .integrals import HostIntegralEngine
 
 
@@ -83,7 +83,10 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
         pq = packed_pq_lists(sd)
         jc_timing.timings[JCTC.screening_time] = time.perf_counter() - t0
         jc_timing.non_timing_data[JCTC.screened_indices_count] = str(int(mask.sum()))
-    fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq)
+    # df_exchange_screen (ScreenedDF.jl:431-447, 459-545): meaningful on the packed map only (a dense map keeps every block)
+    xs = exchange_screen_blocks(opts) if not dense else 0
+    jc_timing.non_timing_data["df_exchange_screen_blocks"] = str(xs)
+    fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq, exchange_screen_blocks=xs)
     fb.set_metric(J2c)
     fb.set_core_hamiltonian(H)
     t_eri = 0.0

@@ -250,6 +250,49 @@ def calculate_K_lower_diagonal_block_no_screen(W: np.ndarray, n_blocks: int) -> 
     return F
 
 
+def exchange_block_screen(mask: np.ndarray, n_blocks: int, screen: bool = True) -> Tuple[int, int, np.ndarray]:
+    """(K_block_width, n_blocks, block_screen_matrix) of calculate_exchange_block_screen_matrix, ScreenedDF.jl:385-457:
+    block (pp >= qq) of the lower triangle is kept when basis_function_screen_matrix has a true entry inside
+    [p_range, q_range] (:435-441), or always without df_screen_exchange (:443-445).  N < 100: one block (:392-394)."""
+    n = mask.shape[0]
+    bw, n_blocks, idx = calculate_exchange_block_screen_matrix(n, n_blocks)
+    bs = np.zeros((n_blocks, n_blocks), dtype=bool)
+    for (pp, qq) in idx:
+        if not screen or mask[pp * bw:(pp + 1) * bw, qq * bw:(qq + 1) * bw].sum() != 0:
+            bs[pp, qq] = True
+    return bw, n_blocks, bs
+
+
+def calculate_K_lower_diagonal_block(W: np.ndarray, sd: ScreeningData, n_blocks: int) -> np.ndarray:
+    """The df_exchange_screen form of the exchange (ScreenedDF.jl:459-545): only the kept blocks of the lower triangle
+    are computed (-W^T W, assigned and mirrored, :488-508), then the ragged strip of N mod n_blocks columns against all
+    rows (:518-545).  Returned on a FRESH (zero) two_electron_fock, i.e. what iteration 1 leaves: the reference's skipped
+    blocks are never written, so from iteration 2 on they would carry the previous iteration's DIIS-mixed entries plus
+    another H (DensityFitting.jl:62-65) - a defect of the snapshot (SURVEY Appendix B rule: not replicated); zero is the
+    value the algorithm means (no kept pair in the block: K screened, J absent)."""
+    Q, o, n = W.shape
+    W2 = W.reshape(Q * o, n)
+    bw, n_blocks, bs = exchange_block_screen(sd.basis_function_screen_matrix, n_blocks, True)
+    F = np.zeros((n, n))
+    for pp in range(n_blocks):
+        for qq in range(pp + 1):
+            if not bs[pp, qq]:
+                continue
+            pr = slice(pp * bw, (pp + 1) * bw)
+            qr = slice(qq * bw, (qq + 1) * bw)
+            blk = -(W2[:, pr].T @ W2[:, qr])
+            F[pr, qr] = blk
+            if pp != qq:
+                F[qr, pr] = blk.T
+    rem = n % n_blocks
+    if rem != 0:
+        qs = slice(n - rem, n)
+        strip = -(W2.T @ W2[:, qs])
+        F[:, qs] = strip
+        F[qs, :] = strip.T
+    return F
+
+
 def copy_screened_density_to_array(density: np.ndarray, sd: ScreeningData) -> np.ndarray:
     """density_array[map[i,j]] = 2 D~[i,j] (i>j kept), D~[i,i]; every other
     slot stays 0 (ScreenedDF.jl:305-316)."""
@@ -294,12 +337,16 @@ def copy_screened_coulomb_to_fock(F: np.ndarray, J: np.ndarray, sd: ScreeningDat
 
 
 def df_rhf_fock_build_screened(Bp: np.ndarray, C_occ: np.ndarray, sd: ScreeningData,
-                               n_blocks: int = 10) -> np.ndarray:
+                               n_blocks: int = 10, screen_exchange: bool = False) -> np.ndarray:
     """2J - K of the default CPU mode: exchange first (assign, beta=0), then
-    Coulomb added (ScreenedDF.jl:130-131).  Bp: (Q, P) packed; C_occ: (N, o)."""
+    Coulomb added (ScreenedDF.jl:130-131).  Bp: (Q, P) packed; C_occ: (N, o).
+    screen_exchange = scf flag df_exchange_screen (ScreenedDF.jl:231-235)."""
     C_T = np.ascontiguousarray(C_occ.T)
     W = calculate_W_screened(Bp, C_T, sd)
-    F = calculate_K_lower_diagonal_block_no_screen(W, n_blocks)
+    if screen_exchange:
+        F = calculate_K_lower_diagonal_block(W, sd, n_blocks)
+    else:
+        F = calculate_K_lower_diagonal_block_no_screen(W, n_blocks)
     J, _, _ = calculate_coulomb_screened(Bp, C_T, sd)
     copy_screened_coulomb_to_fock(F, J, sd)
     return F

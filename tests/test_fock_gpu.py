@@ -130,6 +130,45 @@ def test_screened_packed_parity(N, Q, o, kept):
     h.close(); h2.close()
 
 
+@pytest.mark.parametrize("N,Q,o,kept,n_blocks", [(300, 64, 20, 0.2, 10), (510, 48, 33, 0.15, 10), (333, 40, 17, -0.1, 8),
+                                                 (140, 50, 9, 0.3, 6), (90, 40, 5, 0.3, 10), (258, 48, 12, 0.12, 4)])
+def test_block_screened_exchange_parity(N, Q, o, kept, n_blocks):
+    """The reference's df_exchange_screen (calculate_exchange_block_screen_matrix + calculate_K_lower_diagonal_block,
+    ScreenedDF.jl:431-447, 459-545) through jcdf_set_exchange_screening: K blocks of width N / n_blocks without a kept
+    pair are not computed and hold K = 0; the ragged strip of N mod n_blocks is always computed; N < 100 is one block.
+    Against the oracle's restatement on band maps and a scattered cluster map; the K kernel must launch fewer 64 x 64
+    blocks than without screening whenever the reference skips blocks."""
+    s = synthetic.make(N, Q, o, seed=21, kept_fraction=abs(kept))
+    if kept < 0:
+        s.mask = synthetic.cluster_mask(N, -kept, np.random.default_rng(7), per_site=3)
+    sd = orc.get_screening_metadata(s.mask)
+    Bp = orc.pack_three_center(orc.calculate_B(s.J2c, s.T), sd)
+    Co = s.C[:, :o]
+    bw, nb, bs = orc.exchange_block_screen(sd.basis_function_screen_matrix, n_blocks, True)
+    skipped = int((~bs[np.tril_indices(nb)]).sum())
+    ref = s.H + orc.df_rhf_fock_build_screened(Bp, Co, sd, n_blocks=n_blocks, screen_exchange=True)
+    ref_noscreen = s.H + orc.df_rhf_fock_build_screened(Bp, Co, sd, n_blocks=n_blocks)
+    out = {}
+    for screen in (False, True):
+        h = jc.JCDFHandle(0)
+        h.set_exchange_screening(n_blocks if screen else 0)
+        h.configure(N, Q, 0, Q, o, sd.pq_p, sd.pq_q)
+        h.set_B(np.asfortranarray(Bp))
+        h.set_core_hamiltonian(s.H)
+        F, _ = h.fock_build(Co)
+        kf = {k["name"]: k for k in h.kernel_stats()}["k_exchange_K"]["flops"]
+        out[screen] = (F, kf)
+        h.close()
+    assert _rel(out[False][0], ref_noscreen) < RTOL
+    assert _rel(out[True][0], ref) < RTOL and np.array_equal(out[True][0], out[True][0].T)
+    if N < 100:
+        assert skipped == 0 and nb == 1 and out[True][1] == out[False][1]
+    else:
+        assert skipped > 0 and np.abs(ref - ref_noscreen).max() > 1e-6      # the option does something on these maps
+        if bw >= 64:
+            assert out[True][1] < out[False][1]                              # whole 64 x 64 blocks of the K kernel are gone
+
+
 def test_second_B_formation_on_one_handle_and_column_setter():
     """A new metric starts a new B (jcdf.h: the first push after jcdf_set_metric zeroes B): forming B twice on one
     configured handle — new geometry, same sizes — must not accumulate onto the old tensor.  Also the device-side

@@ -97,3 +97,29 @@ def test_c_twin_matches_numpy(oracle_c):
     J = np.asfortranarray(s.J2c)
     assert oracle_c.jcdf_oracle_form_B(Q, N * N, J.ctypes.data, T.ctypes.data) == 0
     assert np.allclose(T.reshape(Q, N, N), B, rtol=0, atol=1e-12 * np.abs(B).max())
+
+
+def test_block_screened_exchange_of_the_oracle():
+    """oracle.calculate_K_lower_diagonal_block (ScreenedDF.jl:459-545): equals the unscreened block form wherever the
+    reference's block screen keeps a block or in the ragged strip, and is zero in the skipped blocks."""
+    from juliachem_jl_amd import synthetic
+    N, Q, o, nbk = 143, 20, 6, 7
+    s = synthetic.make(N, Q, o, seed=4, kept_fraction=0.2)
+    sd = orc.get_screening_metadata(s.mask)
+    Bp = orc.pack_three_center(orc.calculate_B(s.J2c, s.T), sd)
+    W = orc.calculate_W_screened(Bp, np.ascontiguousarray(s.C[:, :o].T), sd)
+    full = orc.calculate_K_lower_diagonal_block_no_screen(W, nbk)
+    scr = orc.calculate_K_lower_diagonal_block(W, sd, nbk)
+    bw, nb, bs = orc.exchange_block_screen(sd.basis_function_screen_matrix, nbk, True)
+    assert (bw, nb) == (N // nbk, nbk) and not bs[np.triu_indices(nb, 1)].any() and bs.diagonal().all()
+    assert (~bs[np.tril_indices(nb)]).sum() > 0
+    for pp in range(nb):
+        for qq in range(pp + 1):
+            blk = (slice(pp * bw, (pp + 1) * bw), slice(qq * bw, (qq + 1) * bw))
+            if bs[pp, qq]:
+                assert np.array_equal(scr[blk], full[blk])
+            else:
+                assert not scr[blk].any() and not scr[blk[::-1]].any()
+    assert N % nbk != 0 and np.array_equal(scr[:, nb * bw:], full[:, nb * bw:]) and np.array_equal(scr, scr.T)
+    # one block below N = 100 (ScreenedDF.jl:392-394): nothing can be screened
+    assert orc.exchange_block_screen(np.eye(50, dtype=bool), 10, True)[1] == 1
