@@ -249,13 +249,18 @@ int32_t jcdf_scf_tail_device(void *stream, int64_t n, const double *d_D, const d
                              const int32_t *d_diis_flag, const int32_t *d_eig_err, const int32_t *d_eig_info,
                              const double *d_sp2_info, const double *d_pivot, double *d_work, double *d_out);
 
-/* Orthonormalise o <= 128 row vectors through their Gram matrix, caller-side helper of the SP2 step: d_Y (o x n
- * row-major), d_G = Y Y^T (o x o, lower triangle read) -> d_L (o x o row-major) = Cholesky factor of G, d_Z (o x n
- * row-major) = L^-1 Y (orthonormal rows with the span of Y's), d_pivot[0] = smallest diagonal element of L (<= 0: G was
- * not positive definite and d_Z is meaningless).  Two launches (one workgroup factors in LDS; L^-1 Y by forward
- * substitution, 16 columns per workgroup). */
-int32_t jcdf_orthonormalise_rows_device(void *stream, int64_t o, int64_t n, const double *d_G, const double *d_Y, double *d_Z,
-                                        double *d_L, double *d_pivot);
+/* Orthonormal basis of the span of o row vectors, caller-side helper of the SP2 step (the old occupied orbitals
+ * projected into the new occupied space, Y = (P C_prev)^T), for any number of rows (o <= 4096), without a factorisation: Loewdin (symmetric) orthonormalisation by the
+ * coupled Newton-Schulz iteration for G^{-1/2}, G = Y Y^T — o x o products on the fp64 MFMA cores only (csrc/jcdf_blas.hpp).
+ * d_Y: o rows of length n, row-major with leading dimension ldy, ZERO PADDED to roundup(o, 32) rows and roundup(n, 32)
+ * columns (ldy, ldz >= that, even); d_Z receives Z = G^{-1/2} Y in the same padded shape (rows >= o come out zero).
+ * `iterations` (1..40) steps are enqueued; d_info (4 doubles, device) = {||I - G||_F, steps that were needed (0: the
+ * iteration had not converged to 2e-7 before its last step: reject the result), ||I - Z Y||_F before the last step,
+ * steps run}.  The eigenvalues of G must lie in (0, ~1.6) (orthonormal vectors times a projector: (0, 1]); a row set that
+ * has lost rank never converges and is reported through info[1] = 0.  d_work: jcdf_lowdin_workspace_bytes(o) bytes. */
+int64_t jcdf_lowdin_workspace_bytes(int64_t o);
+int32_t jcdf_lowdin_rows_device(void *stream, int64_t o, int64_t n, const double *d_Y, int64_t ldy, double *d_Z, int64_t ldz,
+                                int32_t iterations, void *d_work, int64_t work_bytes, double *d_info);
 
 /* Alternative to the eigensolve inside the SCF step (optional; SCF.jl:1072-1125 takes the density from eigen()):
  * the spectral projector P onto the n_occ lowest eigenvectors of the symmetric matrix d_F (n x n, device,

@@ -75,7 +75,8 @@ PROTOTYPES = {
     "jcdf_stedc_workspace_bytes": (_I64, [_I64]),
     "jcdf_stedc_device": (C.c_int32, [_P, _I64, _P, _P, _P, _I64, _P, _I64]),
     "jcdf_scf_tail_device": (C.c_int32, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "jcdf_orthonormalise_rows_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "jcdf_lowdin_workspace_bytes": (_I64, [_I64]),
+    "jcdf_lowdin_rows_device": (C.c_int32, [_P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P, _I64, _P]),
     "jcdf_sp2_workspace_bytes": (_I64, [_I64]),
     "jcdf_sp2_device": (C.c_int32, [_P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P, _I64, _P]),
     "jcdf_gemm_tn_device": (C.c_int32, [_P, _I64, _I64, _I64, C.c_double, _P, _I64, _P, _I64, _P, _I64]),

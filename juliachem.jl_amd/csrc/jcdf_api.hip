@@ -714,11 +714,12 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_chol_diag, CHOL_DIAG_LDS);
     set((const void *)k_chol_inv_gemm, C64Cfg::SMEM_BYTES);
     set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
-    set((const void *)k_chol_small, 128 * 129 * 8);
-    set((const void *)k_trsm_small, (128 * 129 + 128 * 17) * 8);
     set((const void *)k_dc_update_mfma, DcCfg::SMEM_BYTES);
     set((const void *)k_dc_prepare, 64 * 1024);
     set((const void *)k_blas_gemm_tn, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_ns_gemm, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_sp2_fused<Sp2Cfg>, Sp2Cfg::SMEM_BYTES);
+    set((const void *)k_sp2_fused<Sp2Cfg64>, Sp2Cfg64::SMEM_BYTES);
     set((const void *)k_blas_gemm_nt, GemmNT<BlasNTCfg>::SMEM_BYTES);
     return first;
 }
@@ -1756,32 +1757,21 @@ int32_t jcdf_scf_tail_device(void *stream, int64_t n, const double *d_D, const d
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
-int32_t jcdf_orthonormalise_rows_device(void *stream, int64_t o, int64_t n, const double *d_G, const double *d_Y, double *d_Z,
-                                        double *d_L, double *d_pivot)
-{
-    if (o < 1 || o > 128 || n < 1 || !d_G || !d_Y || !d_Z || !d_L || !d_pivot) return JCDF_ERR_INVALID;
-    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), (size_t)o * (o + 1) * 8, st, d_G, o, (int)o, d_L, o, d_pivot);
-    hipLaunchKernelGGL(k_trsm_small, dim3((unsigned)((n + 15) / 16)), dim3(256), ((size_t)o * (o + 1) + (size_t)o * 17) * 8, st, d_L, o,
-                       (int)o, d_Y, n, (int)n, d_Z, n);
-    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
-}
-
 // ---- SP2 density solver (jcdf_sp2.hpp) -----------------------------------------------------------
 namespace {
 struct Sp2Work {
     double *Xa, *Xb, *part, *partials;
     Sp2State *state;
     int64_t np, ld, bytes;
-    int chunks, ntri;
+    int chunks, ntri, tile;
 };
 Sp2Work sp2_carve(char *base, int64_t n)
 {
     Sp2Work w;
     w.np = roundup(n, SP2_PAD);
     w.ld = w.np;
-    const int nt = (int)(w.np / SP2_T);
+    w.tile = w.np >= SP2_T64_MIN_NP ? 64 : 32;
+    const int nt = (int)(w.np / w.tile);
     w.ntri = nt * (nt + 1) / 2;
     w.chunks = (int)(w.np / Sp2Cfg::KC);
     size_t off = 0;
@@ -1815,9 +1805,15 @@ int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_
     hipLaunchKernelGGL(k_sp2_bounds, dim3(nb), dim3(256), 0, st, d_F, ldf, (int)n, w.part);
     hipLaunchKernelGGL(k_sp2_init, dim3((unsigned)w.np), dim3(256), 0, st, d_F, ldf, (int)n, (int)w.np, w.part, nb, w.Xa, w.ld, w.state,
                        w.partials);
-    for (int k = 0; k < iterations; ++k)
-        hipLaunchKernelGGL(k_sp2_fused, dim3((unsigned)w.ntri), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb, w.ld,
-                           (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    for (int k = 0; k < iterations; ++k) {
+        if (w.tile == 64)
+            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg64>, dim3((unsigned)w.ntri), dim3(Sp2Cfg64::NT), Sp2Cfg64::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa,
+                               w.Xb, w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
+        else
+            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg>, dim3((unsigned)w.ntri), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb,
+                               w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
+    }
     hipLaunchKernelGGL(k_sp2_finish, dim3((unsigned)std::min<int64_t>(n, 512)), dim3(256), 0, st, w.Xa, w.Xb, w.ld, (int)n, d_P, ldp,
                        w.state, (int)iterations, d_info);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
@@ -1932,6 +1928,74 @@ int32_t jcdf_gemm_nt_device(void *stream, int64_t M, int64_t N, int64_t K, const
     const int n_tn = (int)(N / 32);
     hipLaunchKernelGGL(k_blas_gemm_nt, dim3((unsigned)((M / 32) * n_tn)), dim3(BlasNTCfg::NT), GemmNT<BlasNTCfg>::SMEM_BYTES,
                        (hipStream_t)stream, d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 16), n_tn);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+// ---- Loewdin orthonormalisation of row vectors by Newton-Schulz (jcdf_blas.hpp) ----------------------------------------------
+namespace {
+constexpr int LOWDIN_MAX_ITER = 40;
+struct LowdinWork {
+    double *G0, *Y[2], *Yt[2], *Z[2], *Zt[2], *T, *Tt, *part0, *part;
+    int64_t op, bytes;
+    int ntile, n0;
+};
+LowdinWork lowdin_carve(char *base, int64_t o)
+{
+    LowdinWork w;
+    w.op = roundup(o, 32);
+    w.ntile = (int)((w.op / 32) * (w.op / 32));
+    w.n0 = (int)((w.op * w.op + 255) / 256);
+    size_t off = 0;
+    auto take = [&](size_t doubles) { char *p = base ? base + off : nullptr; off += (size_t)roundup((int64_t)doubles * 8, 256); return (double *)p; };
+    const size_t m = (size_t)w.op * w.op;
+    w.G0 = take(m);
+    for (int k = 0; k < 2; ++k) { w.Y[k] = take(m); w.Yt[k] = take(m); w.Z[k] = take(m); w.Zt[k] = take(m); }
+    w.T = take(m); w.Tt = take(m);
+    w.part0 = take((size_t)w.n0);
+    w.part = take((size_t)LOWDIN_MAX_ITER * w.ntile);
+    w.bytes = (int64_t)off;
+    return w;
+}
+}  // namespace
+
+int64_t jcdf_lowdin_workspace_bytes(int64_t o)
+{
+    if (o <= 0) return 0;
+    return lowdin_carve(nullptr, o).bytes;
+}
+
+int32_t jcdf_lowdin_rows_device(void *stream, int64_t o, int64_t n, const double *d_Y, int64_t ldy, double *d_Z, int64_t ldz,
+                                int32_t iterations, void *d_work, int64_t work_bytes, double *d_info)
+{
+    if (o < 1 || o > 4096 || n < 1 || !d_Y || !d_Z || !d_work || !d_info || iterations < 1 || iterations > LOWDIN_MAX_ITER) return JCDF_ERR_INVALID;
+    const int64_t np = roundup(n, 32);
+    if (ldy < np || ldz < np || (ldy & 1) || (ldz & 1)) return JCDF_ERR_INVALID;
+    LowdinWork w = lowdin_carve((char *)d_work, o);
+    if (work_bytes < w.bytes) return JCDF_ERR_INVALID;
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const int op = (int)w.op, n_t = op / 32;
+    const int64_t ld = op;
+    // G = Y Y^T on the NT core (rows of Y are k-contiguous; the zero padding of Y adds nothing)
+    hipLaunchKernelGGL(k_blas_gemm_nt, dim3((unsigned)(n_t * n_t)), dim3(BlasNTCfg::NT), GemmNT<BlasNTCfg>::SMEM_BYTES, st, d_Y, ldy, d_Y, ldy,
+                       w.G0, ld, (int)(np / 16), n_t);
+    // Y_0 = Y_0^T = G (lower triangle mirrored: exactly symmetric, unit diagonal in the padding), Z_0 = Z_0^T = I
+    hipLaunchKernelGGL(k_lowdin_prepare, dim3((unsigned)w.n0), dim3(256), 0, st, w.G0, w.Y[0], w.Yt[0], w.Z[0], w.Zt[0], (int)o, op, w.part0);
+    int c = 0;
+    const NsProblem none{nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < iterations; ++k) {
+        // T = (3 I - Z Y) / 2 with the residual ||T - I||_F^2 per tile;  Y' = Y T and Z' = T Z in one launch
+        hipLaunchKernelGGL(k_ns_gemm, dim3((unsigned)w.ntile, 1), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st,
+                           NsProblem{w.Zt[c], w.Y[c], w.T, w.Tt}, none, ld, op / 32, n_t, -0.5, 1.5, w.part + (int64_t)k * w.ntile);
+        hipLaunchKernelGGL(k_ns_gemm, dim3((unsigned)w.ntile, 2), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st,
+                           NsProblem{w.Yt[c], w.T, w.Y[c ^ 1], w.Yt[c ^ 1]}, NsProblem{w.Tt, w.Z[c], w.Z[c ^ 1], w.Zt[c ^ 1]}, ld, op / 32, n_t, 1.0,
+                           0.0, (double *)nullptr);
+        c ^= 1;
+    }
+    // out[i][col] = sum_k Z[i][k] Y[k][col] = sum_k Zt[k][i] Y[k][col]
+    hipLaunchKernelGGL(k_blas_gemm_tn, dim3((unsigned)(n_t * (np / 32))), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st, w.Zt[c], ld, d_Y, ldy, d_Z,
+                       ldz, op / 32, 1.0, (int)(np / 32));
+    hipLaunchKernelGGL(k_lowdin_info, dim3(1), dim3(64), 0, st, w.part0, w.n0, w.part, w.ntile, (int)iterations, d_info);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

@@ -47,6 +47,112 @@ __global__ __launch_bounds__(BlasNTCfg::NT) void k_blas_gemm_nt(const double *__
     for (int j = 0; j < 4; ++j) C[(int64_t)(tm * 32 + tile_row<Cfg>(0, j)) * ldc + col] = acc[0][0][j];
 }
 
+// C = alpha A^T B + diag I for square operands, written in BOTH orientations: C[tm][tn] and Ct[tn][tm] = C^T — so that a
+// chain of products never needs an explicit transpose (TN core: the left factor enters transposed).  Two independent
+// problems per launch (blockIdx.y); optional per-tile partial sum of ||C - I||_F^2.  smem after the product: 32 x 33 doubles.
+struct NsProblem { const double *At, *B; double *C, *Ct; };
+__global__ __launch_bounds__(BlasTNCfg::NT) void k_ns_gemm(NsProblem p0, NsProblem p1, int64_t ld, int kchunks, int n_tn, double alpha, double diag,
+                                                           double *__restrict__ part)
+{
+    using Cfg = BlasTNCfg;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[256];
+    const NsProblem pr = blockIdx.y ? p1 : p0;
+    const int tm = blockIdx.x / n_tn, tn = blockIdx.x % n_tn;
+    double4_t acc[1][1];
+    acc[0][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_tn_core<Cfg, false, 0, 2>(pr.At + tm * 32, ld, pr.B + tn * 32, ld, kchunks, acc, smem);
+    __syncthreads();
+    double (*T)[33] = reinterpret_cast<double (*)[33]>(smem);
+    const int col = tile_col<Cfg>(0);
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = tile_row<Cfg>(0, j);
+        const bool on_diag = tm == tn && row == col;
+        const double v = alpha * acc[0][0][j] + (on_diag ? diag : 0.0);
+        pr.C[(int64_t)(tm * 32 + row) * ld + tn * 32 + col] = v;
+        T[col][row] = v;
+        const double e = v - (on_diag ? 1.0 : 0.0);
+        s += e * e;
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x >> 3, rr = (threadIdx.x & 7) * 4;            // row c of the transposed tile, 4 of its columns
+        double *dst = pr.Ct + (int64_t)(tn * 32 + c) * ld + tm * 32 + rr;
+        *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
+        *reinterpret_cast<double2_t *>(dst + 2) = double2_t{T[c][rr + 2], T[c][rr + 3]};
+    }
+    if (part) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+    }
+}
+
+// ---- Loewdin orthonormalisation of o row vectors by Newton-Schulz (caller-side helper of the SP2 step for any number of
+// occupied orbitals; the one-workgroup Cholesky of jcdf_scf.hpp holds at most 128 rows in LDS) ------------------------------
+// Y (o x n rows, zero padded to op x np): G = Y Y^T;  coupled iteration Y_0 = G, Z_0 = I, T_k = (3 I - Z_k Y_k) / 2,
+// Y_{k+1} = Y_k T_k, Z_{k+1} = T_k Z_k  ->  Z -> G^{-1/2} (quadratically once ||I - Z Y|| < 1; the eigenvalues of G are
+// the cos^2 of the angles between the old and the new occupied space, in (0, 1]);  out = Z Y: orthonormal rows with the
+// span of Y's, and of all such bases the one closest to Y.  Everything is an op x op product on the MFMA cores.
+// The products are taken as written (k_ns_gemm keeps every iterate in both orientations): this coupled form is the
+// numerically stable one (Higham 1997).  Measured alternatives that are NOT: A^T B in place of A B for the nearly
+// symmetric factors amplifies the antisymmetric rounding error by 3/2 per step (3e-10 after 40 steps), and forcing
+// symmetry by mirroring the lower triangle of each product makes the converged iteration drift away again (residual
+// 1e-15 at step 12, 5e-4 at step 40).
+// k_lowdin_prepare: Y_0 = Y_0^T = G made exactly symmetric (lower triangle mirrored) and padded with a unit diagonal (rows >= o
+// are zero rows of Y), Z_0 = Z_0^T = I, ||I - G||_F^2 partial sums.
+__global__ __launch_bounds__(256) void k_lowdin_prepare(const double *__restrict__ Gin, double *__restrict__ Y, double *__restrict__ Yt,
+                                                        double *__restrict__ Z, double *__restrict__ Zt, int o, int op, double *__restrict__ part)
+{
+    __shared__ double red[256];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (idx < (int64_t)op * op) {
+        const int r = (int)(idx / op), c = (int)(idx % op);
+        double g = (r >= c) ? Gin[idx] : Gin[(int64_t)c * op + r];
+        if (r >= o && r == c) g = 1.0;
+        Y[idx] = Yt[idx] = g;
+        Z[idx] = Zt[idx] = (r == c) ? 1.0 : 0.0;
+        const double d = ((r == c) ? 1.0 : 0.0) - g;
+        s = d * d;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// info = {||I - G||_F, iterations needed (first k with ||I - Z_k Y_k||_F < 2e-7, + 1; 0: not reached), ||I - Z Y||_F before the
+// last step, iterations run}.  Fixed-order sums (bit-reproducible).
+__global__ __launch_bounds__(64) void k_lowdin_info(const double *__restrict__ part0, int n0, const double *__restrict__ part, int ntile,
+                                                    int iterations, double *__restrict__ info)
+{
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n0; ++i) s += part0[i];
+    info[0] = sqrt(s);
+    int used = 0;
+    double last = 0.0;
+    for (int k = 0; k < iterations; ++k) {
+        double r = 0.0;
+        for (int t = 0; t < ntile; ++t) r += part[(int64_t)k * ntile + t];
+        last = 2.0 * sqrt(r);
+        if (!used && last < 2e-7) used = k + 1;
+    }
+    info[1] = (double)used;
+    info[2] = last;
+    info[3] = (double)iterations;
+}
+
 // DIIS bookkeeping of one iteration: e = T^T - T (T = S D F = (F D S)^T, ld), packed N x N into slot `head` of the error
 // history, the Fock matrix into slot `head` of the Fock history.
 __global__ __launch_bounds__(256) void k_diis_push(const double *__restrict__ T, const double *__restrict__ F, int64_t ld, int n,

@@ -74,72 +74,6 @@ __global__ __launch_bounds__(64) void k_scf_tail_final(const double *__restrict_
 
 namespace jcdf {
 
-// Orthonormalisation of o <= 128 row vectors through their Gram matrix (the SP2 step's basis: rocSOLVER potf2 +
-// rocBLAS trtri/trsm are ~20 launches and 0.17 ms there), two launches:
-//   k_chol_small  one workgroup: G = L L^T in LDS, right-looking, ONE barrier per column (the column is used unscaled by
-//                 the trailing update, every thread scaling by 1/sqrt(pivot) itself, and is scaled afterwards — no later
-//                 step reads it);  L (o x o row-major, lower) and pivot[0] = min diag L (<= 0: not positive definite)
-//   k_trsm_small  Z = L^-1 Y for 16 columns of Y (o x n) per workgroup: L and the column block in LDS, forward
-//                 substitution with one barrier per row.
-__global__ __launch_bounds__(256) void k_chol_small(const double *__restrict__ G, int64_t ldg, int o, double *__restrict__ L, int64_t ldl,
-                                                    double *__restrict__ pivot)
-{
-    extern __shared__ __align__(16) double sm[];
-    const int lds = o + 1;
-    double *A = sm;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    for (int idx = tid; idx < o * o; idx += 256) {
-        const int i = idx / o, k = idx % o;
-        A[i * lds + k] = (k <= i) ? G[(int64_t)i * ldg + k] : 0.0;
-    }
-    double piv = 1e300;
-    for (int j = 0; j < o; ++j) {
-        __syncthreads();
-        if (j > 0) {                                              // scale the previous column now that nobody reads it unscaled
-            const double dp = A[(j - 1) * lds + (j - 1)];
-            const double ip = dp > 0.0 ? 1.0 / sqrt(dp) : 1.0;
-            for (int i = j + tid; i < o; i += 256) A[i * lds + (j - 1)] *= ip;
-        }
-        const double d = A[j * lds + j];
-        piv = fmin(piv, d > 0.0 ? sqrt(d) : -1.0);
-        const double inv2 = d > 0.0 ? 1.0 / d : 1.0;              // (l_ij / s)(l_kj / s) = l_ij l_kj / d
-        for (int i = j + 1 + ty; i < o; i += 16) {
-            const double lij = A[i * lds + j] * inv2;
-            for (int k = j + 1 + tx; k <= i; k += 16) A[i * lds + k] -= lij * A[k * lds + j];
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < o * o; idx += 256) {
-        const int i = idx / o, k = idx % o;
-        double v = 0.0;
-        if (k < i) v = (k == o - 1) ? 0.0 : A[i * lds + k];       // columns < o-1 were scaled in the loop
-        if (k == i) { const double d = A[i * lds + i]; v = d > 0.0 ? sqrt(d) : 1.0; }
-        L[(int64_t)i * ldl + k] = v;
-    }
-    if (tid == 0) pivot[0] = piv;
-}
-
-__global__ __launch_bounds__(256) void k_trsm_small(const double *__restrict__ L, int64_t ldl, int o, const double *__restrict__ Y,
-                                                    int64_t ldy, int n, double *__restrict__ Z, int64_t ldz)
-{
-    extern __shared__ __align__(16) double sm[];
-    const int lds = o + 1;
-    double *A = sm, *B = sm + (size_t)o * lds;                   // B: o x 17
-    const int tid = threadIdx.x, c = tid & 15, r0 = tid >> 4;
-    const int col = blockIdx.x * 16 + c;
-    for (int idx = tid; idx < o * o; idx += 256) {
-        const int i = idx / o, k = idx % o;
-        A[i * lds + k] = L[(int64_t)i * ldl + k];
-    }
-    for (int i = r0; i < o; i += 16) B[i * 17 + c] = (col < n) ? Y[(int64_t)i * ldy + col] : 0.0;
-    for (int j = 0; j < o; ++j) {
-        __syncthreads();
-        const double z = B[j * 17 + c] / A[j * lds + j];
-        if (r0 == 0 && col < n) Z[(int64_t)j * ldz + col] = z;
-        for (int i = j + 1 + r0; i < o; i += 16) B[i * 17 + c] -= A[i * lds + j] * z;
-    }
-}
-
 #ifdef JCDF_DIAGNOSTIC
 // ---- k_keepalive: waves that keep the CUs occupied for a given time (experiment: what the clock governor looks at) ----------
 // After ~1 ms without load on most CUs (the replicated eigensolve: 64 polling workgroups) the next Fock build runs 11-17 %

@@ -28,7 +28,10 @@
 namespace jcdf {
 
 typedef GemmCfg<1, 1, 2, 2, 32> Sp2Cfg;          // 32 x 32 tile, 4 waves of 16 x 16, 32 k rows per LDS stage
-constexpr int SP2_T = 32;                        // tile edge
+typedef GemmCfg<2, 2, 2, 2, 32> Sp2Cfg64;        // 64 x 64 tile, 4 waves of 32 x 32: half the operand traffic per flop.  From n ~ 960
+                                                 // on (>= 120 lower tiles) the 32 x 32 form is bound by the L2 (n = 1280: 820 workgroups
+                                                 // x 655 KB of operands per squaring, 59 us)
+constexpr int SP2_T64_MIN_NP = 960;
 constexpr int SP2_PAD = 64;                      // matrices are padded to a multiple of this
 constexpr int SP2_PART = 8448;                   // partial-sum slots per parity: padded rows (first launch) or lower tiles
 
@@ -170,15 +173,17 @@ __device__ __forceinline__ void sp2_tile(int tile, int &ti, int &tj)
     tj = tile - ti * (ti + 1) / 2;
 }
 
-// One squaring = ONE launch, no split-K: workgroup = one 32 x 32 lower tile over the whole contraction length, so the
-// tile it computes is final and the update (decision from the previous launch's partial sums, X_{k+1} tile, mirror image,
+// One squaring = ONE launch, no split-K: workgroup = one T x T lower tile (T = 32 or 64) over the whole contraction length, so
+// the tile it computes is final and the update (decision from the previous launch's partial sums, X_{k+1} tile, mirror image,
 // partial sums for the next launch) is its epilogue.  State, partial sums and the thread's own X elements are loaded
 // before the operand stream starts and used after it.
-
-__global__ __launch_bounds__(Sp2Cfg::NT) void k_sp2_fused(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
-                                                               double *Xb_w, int64_t ld, int n_occ, int chunks, double *partials,
-                                                               int npart0, int ntri, Sp2State *state, int k)
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
+                                                       double *Xb_w, int64_t ld, int n_occ, int chunks, double *partials,
+                                                       int npart0, int ntri, Sp2State *state, int k)
 {
+    constexpr int TS = Cfg::TM, WM = Cfg::WM, WN = Cfg::WN;
+    static_assert(Cfg::TM == Cfg::TN && Cfg::NT == 256, "square tiles, 4 waves");
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[2][256];
     const double *X = (k & 1) ? Xb : Xa;
@@ -196,36 +201,50 @@ __global__ __launch_bounds__(Sp2Cfg::NT) void k_sp2_fused(const double *__restri
         tx += v[0];
         t2 += v[1];
     }
-    const int col = tile_col<Sp2Cfg>(0);
-    double x[4];
+    double x[WM][WN][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = X[(int64_t)(ti * SP2_T + tile_row<Sp2Cfg>(0, j)) * ld + tj * SP2_T + col];
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                x[m][n][j] = X[(int64_t)(ti * TS + tile_row<Cfg>(m, j)) * ld + tj * TS + tile_col<Cfg>(n)];
     if (st.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) state[(k + 1) & 1] = st;
         return;
     }
-    double4_t acc[1][1];
-    acc[0][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_tn_core<Sp2Cfg, false, 0, 2>(X + ti * SP2_T, ld, X + tj * SP2_T, ld, chunks, acc, smem);
+    double4_t acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_tn_core<Cfg, false, 0, 2>(X + ti * TS, ld, X + tj * TS, ld, chunks, acc, smem);
     const Sp2Decision d = sp2_decide(st, tx, t2, n_occ, red);
-    double (*T)[SP2_T + 1] = reinterpret_cast<double (*)[SP2_T + 1]>(smem);      // the GEMM stages are free now
+    double (*T)[TS + 1] = reinterpret_cast<double (*)[TS + 1]>(smem);      // the GEMM stages are free now (sp2_decide ends on a barrier)
     double ptr = 0.0, pfro = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = tile_row<Sp2Cfg>(0, j);
-        const double q = acc[0][0][j];
-        const double v = d.branch ? (2.0 * x[j] - q) : q;
-        Xn[(int64_t)(ti * SP2_T + row) * ld + tj * SP2_T + col] = v;
-        T[col][row] = v;
-        pfro += v * v;
-        if (ti == tj && row == col) ptr += v;
-    }
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = tile_row<Cfg>(m, j), col = tile_col<Cfg>(n);
+                const double q = acc[m][n][j];
+                const double v = d.branch ? (2.0 * x[m][n][j] - q) : q;
+                Xn[(int64_t)(ti * TS + row) * ld + tj * TS + col] = v;
+                T[col][row] = v;
+                pfro += v * v;
+                if (ti == tj && row == col) ptr += v;
+            }
     if (ti != tj) {
         __syncthreads();
-        const int c = threadIdx.x >> 3, rr = (threadIdx.x & 7) * 4;       // mirrored: row c of tile (tj, ti), 4 of its 32 columns
-        double *dst = Xn + (int64_t)(tj * SP2_T + c) * ld + ti * SP2_T + rr;
-        *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
-        *reinterpret_cast<double2_t *>(dst + 2) = double2_t{T[c][rr + 2], T[c][rr + 3]};
+        // mirrored tile (tj, ti): row c, 4 consecutive columns per thread and pass
+        for (int e = threadIdx.x; e < TS * TS / 4; e += 256) {
+            const int c = e / (TS / 4), rr = (e % (TS / 4)) * 4;
+            double *dst = Xn + (int64_t)(tj * TS + c) * ld + ti * TS + rr;
+            *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
+            *reinterpret_cast<double2_t *>(dst + 2) = double2_t{T[c][rr + 2], T[c][rr + 3]};
+        }
         pfro *= 2.0;
     }
     __syncthreads();

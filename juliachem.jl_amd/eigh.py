@@ -223,7 +223,8 @@ class DeviceSP2:
     Optional replacement of the per-iteration eigensolve in DeviceSCF (scf flag density_solver = "sp2"): the SCF
     energy, density and DIIS error depend on the occupied SPACE only (SCF.jl:1072-1125 forms D = 2 C_o C_o^T).
     No host round trip: `iterations` squarings are enqueued (adapted from the count the previous call needed),
-    `info` stays on the device for the caller's one copy per SCF iteration."""
+    `info` stays on the device for the caller's one copy per SCF iteration.  P comes back zero padded (npad x npad,
+    npad = n rounded up to 32): the operand shape of the library's GEMM cores."""
 
     def __init__(self, n: int, n_occ: int, device: torch.device):
         self.n, self.n_occ, self.device = n, n_occ, device
@@ -231,18 +232,21 @@ class DeviceSP2:
         f64 = dict(dtype=torch.float64, device=device)
         self.wb = int(self.lib.jcdf_sp2_workspace_bytes(n))
         self.work = torch.zeros(self.wb // 8 + 8, **f64)
-        self.P = torch.empty((n, n), **f64)
+        self.npad = (n + 31) // 32 * 32
+        self.Pp = torch.zeros((self.npad, self.npad), **f64)
+        self.P = self.Pp[:n, :n]
         self.info = torch.zeros(8, **f64)
-        self.iterations = int(os.environ.get("JCDF_SP2_ITERATIONS", "72"))
-        self.fixed = "JCDF_SP2_ITERATIONS" in os.environ
+        self.iterations = 72
         self.calls = 0
 
     def __call__(self, Fp: torch.Tensor, iterations: Optional[int] = None) -> torch.Tensor:
+        """Fp: symmetric (n, n) device tensor or view (row stride = its leading dimension).  Returns the (n, n) view of Pp."""
         self.calls += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
-        Fp = Fp.contiguous()
-        rc = self.lib.jcdf_sp2_device(C.c_void_p(st), self.n, self.n_occ, C.c_void_p(Fp.data_ptr()), self.n,
-                                      C.c_void_p(self.P.data_ptr()), self.n, int(iterations or self.iterations),
+        if Fp.stride(1) != 1:
+            Fp = Fp.contiguous()
+        rc = self.lib.jcdf_sp2_device(C.c_void_p(st), self.n, self.n_occ, C.c_void_p(Fp.data_ptr()), Fp.stride(0),
+                                      C.c_void_p(self.Pp.data_ptr()), self.npad, int(iterations or self.iterations),
                                       C.c_void_p(self.work.data_ptr()), self.wb, C.c_void_p(self.info.data_ptr()))
         if rc != 0:
             raise RuntimeError("jcdf_sp2_device failed (status %d)" % rc)
@@ -250,6 +254,33 @@ class DeviceSP2:
 
     def adapt(self, used: float, finished: bool) -> None:
         """after the caller has read info: enqueue (needed + 4) squarings next time, at least 16, more after a miss"""
-        if self.fixed:
-            return
         self.iterations = min(400, max(16, int(used) + 4)) if finished else min(400, 2 * self.iterations)
+
+
+class DeviceLowdin:
+    """Orthonormal basis of the span of o row vectors (`jcdf_lowdin_rows_device`, csrc/jcdf_blas.hpp: Loewdin
+    orthonormalisation by Newton-Schulz, products on the MFMA cores) for the SP2 step of DeviceSCF: Y = (P Cp)^T holds the old
+    occupied orbitals projected into the new occupied space.  Buffers are (op x npad) zero padded.  `steps` Newton-Schulz steps
+    are enqueued (adapted from what the previous call needed); info[1] (device) = steps needed, 0 = not converged."""
+
+    def __init__(self, o: int, n: int, device: torch.device):
+        self.o, self.n, self.device = o, n, device
+        self.lib = _lib.load()
+        f64 = dict(dtype=torch.float64, device=device)
+        self.op, self.npad = (o + 31) // 32 * 32, (n + 31) // 32 * 32
+        self.wb = int(self.lib.jcdf_lowdin_workspace_bytes(o))
+        self.work = torch.zeros(self.wb // 8 + 8, **f64)
+        self.info = torch.zeros(4, **f64)
+        self.steps = 12
+
+    def __call__(self, Yp: torch.Tensor, out: torch.Tensor) -> None:
+        assert Yp.shape == (self.op, self.npad) and out.shape == (self.op, self.npad) and Yp.is_contiguous() and out.is_contiguous()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.jcdf_lowdin_rows_device(C.c_void_p(st), self.o, self.n, C.c_void_p(Yp.data_ptr()), self.npad, C.c_void_p(out.data_ptr()),
+                                              self.npad, int(self.steps), C.c_void_p(self.work.data_ptr()), self.wb, C.c_void_p(self.info.data_ptr()))
+        if rc != 0:
+            raise RuntimeError("jcdf_lowdin_rows_device failed (status %d)" % rc)
+
+    def adapt(self, needed: float) -> None:
+        """needed: info[1] as read by the caller (0: did not converge in the steps enqueued)"""
+        self.steps = min(40, max(3, int(needed) + 2)) if needed >= 1 else min(40, 2 * self.steps)

@@ -101,7 +101,7 @@ class DeviceFockBuilder:
 
     def __init__(self, N: int, Q_total: int, n_occ: int, aux_shell_nbas: Sequence[int],
                  device: Optional[int] = None, pq: Tuple[Optional[np.ndarray], Optional[np.ndarray]] = (None, None),
-                 exchange_screen_blocks: int = 0):
+                 exchange_screen_blocks: int = 0, tuning: Optional[dict] = None):
         self.rank, self.world, self.dist = _dist()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,6 +117,8 @@ class DeviceFockBuilder:
         # that produce its inputs (C_occ, the T blocks) and consume its output (F)
         self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.h.set_exchange_screening(exchange_screen_blocks)      # df_exchange_screen (ScreenedDF.jl:431-447); 0 = off
+        for key, value in (tuning or {}).items():                  # jcdf_set_tuning keys (include/jcdf.h)
+            self.h.set_tuning(key, value)
         self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
         self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
         self.time_collectives = False      # bench: device events around the broadcast of C and the all-reduce of F
@@ -219,13 +221,15 @@ class DeviceSCF:
             raise ValueError("density_solver %r: \"eigh\" or \"sp2\"" % self.density_solver)
         self.sp2 = None
         if self.density_solver == "sp2" and 0 < self.n_occ < self.N and 2 <= self.N <= 4096:     # outside: eigensolver
-            from .eigh import DeviceSP2
+            from .eigh import DeviceLowdin, DeviceSP2
             self.sp2 = DeviceSP2(self.N, self.n_occ, dev)
+            self.lowdin = DeviceLowdin(self.n_occ, self.N, dev)
+            self.Cpt = torch.zeros((self.op, self.Np), **self._f64)     # occupied orbitals in the orthogonal basis (rows), zero padded
+            self.Yt = torch.zeros((self.op, self.Np), **self._f64)
         self.sp2_pivot = None
         self.tail_work = torch.zeros(256, **self._f64)
         self.tail_out = torch.zeros(8, **self._f64)
-        self.sp2_steps = self.sp2_fallbacks = 0
-        self.sp2_two_pass = True
+        self.sp2_steps = self.sp2_fallbacks = self.sp2_basis_retries = 0
         self.sp2_reasons = {}
         self.sp2_skip = True                     # first step, and while the density still changes wholesale: eigensolver
         self.canonical = True                    # self.C / self.eps are the eigenvectors / eigenvalues of self.F
@@ -257,6 +261,16 @@ class DeviceSCF:
                                            ctypes.c_void_p(B.data_ptr()), B.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0))
         if rc != 0:
             raise RuntimeError("jcdf_gemm_tn_device failed (status %d)" % rc)
+        return out
+
+    def _gemm_nt(self, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out[m][n] = sum_k A[m][k] B[n][k] on the library's MFMA core (B symmetric: out = A B)."""
+        M, K = A.shape
+        Nn = B.shape[0]
+        rc = self._lib.jcdf_gemm_nt_device(self._st(), M, Nn, K, ctypes.c_void_p(A.data_ptr()), A.stride(0), ctypes.c_void_p(B.data_ptr()),
+                                           B.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0))
+        if rc != 0:
+            raise RuntimeError("jcdf_gemm_nt_device failed (status %d)" % rc)
         return out
 
     @property
@@ -313,20 +327,14 @@ class DeviceSCF:
         self._gemm_tn(self.Xp, self.T1, self.Fpr)                   # X (F X)
         if use_sp2:
             # occupied-space projector P of F' by spectral projection; orthonormal basis of its range from the previous
-            # occupied orbitals Cp (orthogonal basis): Y = P Cp, Y^T Y = L L^T, Cp_new^T = L^-1 Y^T, so that
-            # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (checked through the pivots).
-            # (optional path: its two thin products and the Gram matrix go through torch)
-            P = self.sp2(self.Fpr[:N, :N])
-            Yt = self.Cp_t @ P                                      # (o, N) = (P Cp)^T
-            Cp_t, pivot = self._orthonormalise(Yt)
-            if self.sp2_two_pass:
-                # the new occupied space has turned far from the old one (small pivots, early iterations): Y^T Y is
-                # ill-conditioned and one Cholesky pass leaves Cp orthonormal only to cond * eps — second pass (CholQR2)
-                Cp_t, _ = self._orthonormalise(Cp_t)
-            self.Cp_t = Cp_t
-            self.Cop[:o, :N].copy_(self.Cp_t @ self.X)              # (o, N): rows = occupied orbitals in the AO basis
-            self.sp2_pivot = pivot
-            self.canonical = False
+            # occupied orbitals Cp (orthogonal basis): Y = P Cp, Cp_new = Y (Y^T Y)^-1/2 (Loewdin), so that
+            # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (the Newton-Schulz iteration for the
+            # inverse square root converges then and only then: its status word goes into the iteration's record).
+            # Every product runs on the library's MFMA cores (jcdf_gemm_nt_device, jcdf_lowdin_rows_device).
+            self.sp2(self.Fpr[:N, :N])                              # -> self.sp2.Pp (Np x Np, zero padded)
+            self._gemm_nt(self.Cpt, self.sp2.Pp, self.Yt)           # (o, N) = (P Cp)^T   (P symmetric)
+            self._sp2_basis()
+            return
         else:
             self.eps, U = self.eigh(self.Fpr[:N, :N])
             Up = self.eigh.U_padded                                 # the library path leaves U zero padded (Np x Np) already
@@ -335,11 +343,22 @@ class DeviceSCF:
                 Up = self.Up
             self._gemm_tn(Up, self.Xp, self.Ctp)                    # (X U)^T[i][m] = sum_k U[k][i] X[k][m]
             if self.sp2 is not None:
-                self.Cp_t = Up[:N, :o].t().contiguous()             # occupied orbitals in the orthogonal basis, (o, N)
+                self.Cpt[:o, :N].copy_(Up[:N, :o].t())              # occupied orbitals in the orthogonal basis, (o, N)
             self.Cop[:o].copy_(self.Ctp[:o])
             self.canonical = True
         self.Co_t = self.Cop[:o, :N].contiguous()                   # (o, N) row-major == (N, o) column-major, for the Fock build
         self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)             # D = 2 Co^T Co (zero rows of Cop add nothing)
+
+    def _sp2_basis(self) -> None:
+        """second half of the SP2 step: orthonormal basis of range(P) from Y = (P Cp)^T (self.Yt is left untouched, so the
+        step can be repeated with more Newton-Schulz steps), orbitals in the AO basis, density."""
+        N, o = self.N, self.n_occ
+        self.lowdin(self.Yt, self.Cpt)
+        self._gemm_nt(self.Cpt, self.Xp, self.Cop)                  # (o, N): rows = occupied orbitals in the AO basis (X symmetric)
+        self.sp2_pivot = self.lowdin.info[1:2]                      # Newton-Schulz steps needed, 0 = no convergence
+        self.canonical = False
+        self.Co_t = self.Cop[:o, :N].contiguous()
+        self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)
 
     def _checked_diag(self) -> None:
         """Eigensolve whose status is read at once (one host sync): used where no scf tail follows — iteration 0 and
@@ -359,23 +378,6 @@ class DeviceSCF:
         return {"eigensolves": e.calls, "library_path": bool(e.ok), "vendor_fallbacks": e.fallbacks,
                 "reason": getattr(e, "reason", None)}
 
-    def _orthonormalise(self, Yt: torch.Tensor):
-        """rows of Yt (o, N) -> L^-1 Yt with Yt Yt^T = L L^T; also the smallest pivot (1-element device tensor)"""
-        o = Yt.shape[0]
-        G = Yt @ Yt.T
-        if o <= 128:
-            Yt = Yt.contiguous()
-            Z = torch.empty_like(Yt)
-            L = torch.empty((o, o), dtype=torch.float64, device=Yt.device)
-            piv = torch.empty(1, dtype=torch.float64, device=Yt.device)
-            p = lambda t: ctypes.c_void_p(t.data_ptr())
-            rc = self._lib.jcdf_orthonormalise_rows_device(self._st(), o, Yt.shape[1], p(G), p(Yt), p(Z), p(L), p(piv))
-            if rc != 0:
-                raise RuntimeError("jcdf_orthonormalise_rows_device failed (status %d)" % rc)
-            return Z, piv
-        L, _ = torch.linalg.cholesky_ex(G)
-        return torch.linalg.solve_triangular(L, Yt, upper=False), torch.diagonal(L).min().reshape(1)
-
     def _tail(self, D_old: torch.Tensor, use_sp2: bool) -> List[float]:
         """E_elec, ||D - D_old|| and the iteration's status words in one 64-byte record (`jcdf_scf_tail_device`), read
         with ONE device-to-host copy — the only host synchronisation of the iteration.  (The padded buffers are summed
@@ -394,7 +396,7 @@ class DeviceSCF:
             trouble = torch.zeros(2, dtype=torch.float64, device=rec.device)
             trouble[0] = (rec[3] != 0).to(torch.float64)
             if use_sp2:
-                good = (rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & (rec[6] > 1e-2) & torch.isfinite(rec[0])
+                good = (rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & (rec[6] >= 1.0) & torch.isfinite(rec[0])
                 trouble[1] = (~good).to(torch.float64)
             _all_reduce(dist, trouble, dist.ReduceOp.MAX)
             _broadcast(dist, rec, 0)
@@ -504,14 +506,26 @@ class DeviceSCF:
             self.B_dim = 2
             self.diis_flag.zero_()
         if use_sp2:
-            good = finished == 1.0 and abs(trace - self.n_occ) < 1e-6 and pivot > 1e-2 and math.isfinite(e_h)
+            proj_ok = finished == 1.0 and abs(trace - self.n_occ) < 1e-6
             self.sp2.adapt(used, finished == 1.0)
-            self.sp2_two_pass = not (pivot > 0.9)                  # next iteration: the spaces turn smoothly
             self.sp2_steps += 1
+            if proj_ok and not pivot >= 1.0 and self.lowdin.steps < 40:
+                # the projector is fine, the Newton-Schulz iteration for the basis had too few steps (the occupied space
+                # turned further than last time): once more with the maximum, before an eigensolve is spent on it
+                self.sp2_basis_retries += 1
+                self.lowdin.steps = 40
+                self._sp2_basis()
+                e_h, drms, _, _, _, _, pivot, _ = self._tail(D_old, True)
+            self.lowdin.adapt(pivot if math.isfinite(pivot) else 0.0)
+            good = proj_ok and pivot >= 1.0 and math.isfinite(e_h)
             if not good:                                           # not converged in the squarings enqueued / basis lost: eigensolve
                 self.sp2_fallbacks += 1
-                why = "unfinished" if finished != 1.0 else "trace" if abs(trace - self.n_occ) >= 1e-6 else "pivot" if not pivot > 1e-2 else "nan"
+                why = "unfinished" if finished != 1.0 else "trace" if abs(trace - self.n_occ) >= 1e-6 else "basis" if not pivot >= 1.0 else "nan"
                 self.sp2_reasons[why] = self.sp2_reasons.get(why, 0) + 1
+                # a projection / orthonormalisation that did not converge may have left non-finite numbers in the zero
+                # padding of the buffers the eigensolver path only partly overwrites
+                self.Cop.zero_()
+                self.Cpt.zero_()
                 self._diag(False)
                 e_h, drms, _, eig_bad = self._tail(D_old, False)[:4]
         if eig_bad:                                                # hand-off timeout / stedc failure on some rank: all ranks redo,

@@ -950,6 +950,33 @@ def test_sp2_reports_unfinished_and_rejects_bad_arguments():
     assert lib.jcdf_sp2_workspace_bytes(0) == 0
 
 
+def test_scf_with_sp2_more_than_128_occupied_orbitals():
+    """The same on a case with more than 128 occupied orbitals — (H2O)27 / cc-pVDZ / cc-pVDZ-RIFIT, 135 occupied, 675 AO
+    (geometry: the first 27 molecules of the reference's (H2O)50 input, tests/golden/w50_geometry.json) — where the
+    occupied basis is orthonormalised by the Newton-Schulz kernel and every product of the step runs on the library's
+    own GEMM cores.  The energy is pinned to nothing but the eigensolver path of the same run (parity unpinned)."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    g = json.load(open(os.path.join(GOLDEN, "w50_geometry.json")))
+    b = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    nw = 27
+    xyz = np.asarray(g["geometry"]).reshape(-1, 3)[:3 * nw] * g["angstrom_to_bohr"]
+    atoms = [{"symbol": s, "center": list(map(float, r))} for s, r in zip(g["symbols"][:3 * nw], xyz)]
+    f = {"dele": 1e-8, "rmsd": 1e-8, "niter": 60}
+    a = rhf.run(atoms, b["charges"], b["basis"], b["aux_basis"], f)
+    c = rhf.run(atoms, b["charges"], b["basis"], b["aux_basis"], dict(f, density_solver="sp2"))
+    assert a["Converged?"] and c["Converged?"] and c["Iterations"] == a["Iterations"]
+    ds = c["Density Solver"]
+    assert ds["name"] == "sp2" and ds["sp2_steps"] - ds["sp2_fallbacks"] >= 8, ds
+    # along the way the two paths stay together to 3e-7 Eh (measured: 2.8e-7 at the first projected step, where the
+    # energy still moves by 7 Eh per iteration and DIIS amplifies a 1e-12 difference of the densities), at the end to 2e-12
+    assert max(abs(x[1] - y[1]) for x, y in zip(a["Trail"], c["Trail"])) < 2e-6
+    assert max(abs(x[1] - y[1]) for x, y in zip(a["Trail"][-8:], c["Trail"][-8:])) < 1e-10
+    assert abs(a["Energy"] - c["Energy"]) < 1e-10 and np.abs(a["Density"] - c["Density"]).max() < 1e-10
+    assert np.abs(a["Orbital Energies"] - c["Orbital Energies"]).max() < 1e-10
+
+
 @pytest.mark.parametrize("case,tol", [("ccpvdz", 1e-9), ("631g2dfp", 1e-7)])
 def test_scf_with_sp2_follows_the_eigensolver_trail(case, tol):
     """density_solver = "sp2": same energies along the whole SCF trail as with the eigensolver (the density depends on
@@ -973,41 +1000,52 @@ def test_scf_with_sp2_follows_the_eigensolver_trail(case, tol):
     assert np.allclose(b["MO Coeff"].T @ b["Fock"] @ b["MO Coeff"], np.diag(b["Orbital Energies"]), atol=1e-8)
 
 
-@pytest.mark.parametrize("o,n,cond", [(1, 3, 1.0), (5, 17, 10.0), (64, 100, 1e3), (81, 510, 1e6), (128, 130, 1e2)])
-def test_orthonormalise_rows_kernel(o, n, cond):
-    """jcdf_orthonormalise_rows_device: Cholesky factor of the Gram matrix in one workgroup + L^-1 Y by forward
-    substitution, against LAPACK; pivot = min diag(L); a Gram matrix that is not positive definite shows in the pivot."""
+@pytest.mark.parametrize("o,n,lmin", [(1, 3, 1.0), (5, 17, 0.5), (64, 100, 0.05), (81, 510, 0.9), (130, 650, 0.3), (250, 1250, 0.8), (300, 301, 1e-3)])
+def test_lowdin_rows_kernel(o, n, lmin):
+    """jcdf_lowdin_rows_device: Z = (Y Y^T)^-1/2 Y by Newton-Schulz on the MFMA cores against numpy's symmetric
+    orthonormalisation (eigendecomposition of the Gram matrix); Gram eigenvalues from lmin to 1 (the cos^2 of the angles
+    between two occupied spaces); zero padding in, zero padding out; a rank-deficient row set is reported, not returned."""
     import ctypes
-    import scipy.linalg
     import torch
-    from juliachem_jl_amd import _lib
-    lib = _lib.load()
+    from juliachem_jl_amd.eigh import DeviceLowdin
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(o)
     U, _ = np.linalg.qr(rng.standard_normal((n, o)))
     W, _ = np.linalg.qr(rng.standard_normal((o, o)))
-    Y = (W * np.geomspace(1.0, cond ** -0.5, o)) @ U.T            # o x n, singular values 1 .. cond^-1/2
-    G = Y @ Y.T
-    Yd, Gd = torch.as_tensor(Y, device=dev), torch.as_tensor(G, device=dev)
-    Z = torch.full((o, n), 7.0, dtype=torch.float64, device=dev)
-    L = torch.full((o, o), 7.0, dtype=torch.float64, device=dev)
-    piv = torch.zeros(1, dtype=torch.float64, device=dev)
+    lam = np.geomspace(1.0, lmin, o)
+    Y = (W * np.sqrt(lam)) @ W.T @ U.T                            # o x n, Gram matrix W diag(lam) W^T
+    lw = DeviceLowdin(o, n, dev)
+    lw.steps = 40
+    Yp = torch.zeros((lw.op, lw.npad), dtype=torch.float64, device=dev)
+    Yp[:o, :n] = torch.as_tensor(Y, device=dev)
+    out = torch.full((lw.op, lw.npad), 7.0, dtype=torch.float64, device=dev)
+    lw(Yp, out)
+    g0, needed, last, ran = lw.info.cpu().tolist()
+    Z = out.cpu().numpy()
+    ev, V = np.linalg.eigh(Y @ Y.T)
+    Zr = (V / np.sqrt(ev)) @ V.T @ Y
+    assert ran == 40 and 1 <= needed <= 40 and last < 2e-7
+    assert abs(g0 - np.linalg.norm(np.eye(o) - Y @ Y.T)) < 1e-12 * max(1.0, g0)
+    assert not Z[o:].any() and not Z[:, n:].any()
+    assert np.abs(Z[:o, :n] - Zr).max() < 1e-12 / lmin
+    assert np.abs(Z[:o, :n] @ Z[:o, :n].T - np.eye(o)).max() < 1e-13 / lmin
+    # fewer steps than needed: reported through info[1] = 0
+    if needed > 3:
+        lw.steps = int(needed) - 2
+        lw(Yp, out)
+        assert lw.info[1].item() == 0.0
+        lw.adapt(0.0)
+        assert lw.steps == 2 * (int(needed) - 2)
+    # a row set that has lost rank never converges
+    if o >= 5:
+        Yp[1] = Yp[0]
+        lw.steps = 40
+        lw(Yp, out)
+        assert lw.info[1].item() == 0.0
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    assert lib.jcdf_orthonormalise_rows_device(st, o, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 0
-    Lr = np.linalg.cholesky(G)
-    Lg, Zg = L.cpu().numpy(), Z.cpu().numpy()
-    assert np.all(np.triu(Lg, 1) == 0.0)
-    assert np.abs(Lg - Lr).max() < 1e-13 * cond ** 0.5
-    assert abs(piv.item() - np.diag(Lr).min()) < 1e-13 * cond ** 0.5
-    Zr = scipy.linalg.solve_triangular(Lr, Y, lower=True)
-    assert np.abs(Zg - Zr).max() < 1e-13 * cond
-    assert np.abs(Zg @ Zg.T - np.eye(o)).max() < 1e-14 * cond * o + 1e-13
-    assert lib.jcdf_orthonormalise_rows_device(st, 129, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 1      # JCDF_ERR_INVALID
-    if o >= 5:
-        Gd[2, 2] = -1.0
-        assert lib.jcdf_orthonormalise_rows_device(st, o, n, p(Gd), p(Yd), p(Z), p(L), p(piv)) == 0
-        assert piv.item() <= 0.0
+    for bad in ((0, n, lw.npad, 5, lw.wb), (o, n, lw.npad - 2, 5, lw.wb), (o, n, lw.npad, 0, lw.wb), (o, n, lw.npad, 41, lw.wb), (o, n, lw.npad, 5, lw.wb - 1)):
+        assert lw.lib.jcdf_lowdin_rows_device(st, bad[0], bad[1], p(Yp), bad[2], p(out), lw.npad, bad[3], p(lw.work), bad[4], p(lw.info)) == 1
 
 
 def test_scf_tail_record():
