@@ -716,7 +716,8 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
     set((const void *)k_dc_update_mfma, DcCfg::SMEM_BYTES);
     set((const void *)k_dc_prepare, 64 * 1024);
-    set((const void *)k_blas_gemm_tn, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_blas_gemm_tn<BlasTNCfg>, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_blas_gemm_tn<BlasTN64Cfg>, BlasTN64Cfg::SMEM_BYTES);
     set((const void *)k_ns_gemm, BlasTNCfg::SMEM_BYTES);
     set((const void *)k_sp2_fused<Sp2Cfg>, Sp2Cfg::SMEM_BYTES);
     set((const void *)k_sp2_fused<Sp2Cfg64>, Sp2Cfg64::SMEM_BYTES);
@@ -1808,10 +1809,10 @@ int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_
     if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
     for (int k = 0; k < iterations; ++k) {
         if (w.tile == 64)
-            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg64>, dim3((unsigned)w.ntri), dim3(Sp2Cfg64::NT), Sp2Cfg64::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa,
+            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg64>, dim3((unsigned)(8 * ((w.ntri + 7) / 8))), dim3(Sp2Cfg64::NT), Sp2Cfg64::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa,
                                w.Xb, w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
         else
-            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg>, dim3((unsigned)w.ntri), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb,
+            hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg>, dim3((unsigned)(8 * ((w.ntri + 7) / 8))), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb,
                                w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
     }
     hipLaunchKernelGGL(k_sp2_finish, dim3((unsigned)std::min<int64_t>(n, 512)), dim3(256), 0, st, w.Xa, w.Xb, w.ld, (int)n, d_P, ldp,
@@ -1912,9 +1913,17 @@ int32_t jcdf_gemm_tn_device(void *stream, int64_t M, int64_t N, int64_t K, doubl
         (lda & 1) || (ldb & 1))
         return JCDF_ERR_INVALID;
     if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
-    const int n_tn = (int)(N / 32);
-    hipLaunchKernelGGL(k_blas_gemm_tn, dim3((unsigned)((M / 32) * n_tn)), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, (hipStream_t)stream,
-                       d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 32), alpha, n_tn);
+    // 64 x 64 tiles (8 waves) once they fill at least half the chip: half the operand traffic of the 32 x 32 form, which
+    // is bound by the L2 from ~1000^3 on
+    if (M % 64 == 0 && N % 64 == 0 && (M / 64) * (N / 64) >= 128) {
+        const int n_tn = (int)(N / 64);
+        hipLaunchKernelGGL(k_blas_gemm_tn<BlasTN64Cfg>, dim3((unsigned)((M / 64) * n_tn)), dim3(BlasTN64Cfg::NT), BlasTN64Cfg::SMEM_BYTES,
+                           (hipStream_t)stream, d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 32), alpha, n_tn);
+    } else {
+        const int n_tn = (int)(N / 32);
+        hipLaunchKernelGGL(k_blas_gemm_tn<BlasTNCfg>, dim3((unsigned)((M / 32) * n_tn)), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES,
+                           (hipStream_t)stream, d_A, lda, d_B, ldb, d_C, ldc, (int)(K / 32), alpha, n_tn);
+    }
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
@@ -1993,8 +2002,8 @@ int32_t jcdf_lowdin_rows_device(void *stream, int64_t o, int64_t n, const double
         c ^= 1;
     }
     // out[i][col] = sum_k Z[i][k] Y[k][col] = sum_k Zt[k][i] Y[k][col]
-    hipLaunchKernelGGL(k_blas_gemm_tn, dim3((unsigned)(n_t * (np / 32))), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st, w.Zt[c], ld, d_Y, ldy, d_Z,
-                       ldz, op / 32, 1.0, (int)(np / 32));
+    hipLaunchKernelGGL(k_blas_gemm_tn<BlasTNCfg>, dim3((unsigned)(n_t * (np / 32))), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st, w.Zt[c], ld, d_Y,
+                       ldy, d_Z, ldz, op / 32, 1.0, (int)(np / 32));
     hipLaunchKernelGGL(k_lowdin_info, dim3(1), dim3(64), 0, st, w.part0, w.n0, w.part, w.ntile, (int)iterations, d_info);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }

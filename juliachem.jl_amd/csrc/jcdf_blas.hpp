@@ -15,21 +15,30 @@ namespace jcdf {
 typedef GemmCfg<1, 1, 2, 2, 32> BlasTNCfg;       // 32 x 32 tile, 4 waves of 16 x 16, 32 k rows per LDS stage
 typedef GemmCfg<1, 1, 2, 2, 16> BlasNTCfg;       // the same tile on the NT core (16 k per stage)
 
-// C[m][n] = alpha * sum_k A[k][m] B[k][n]   (both operands k-major); M, N, K multiples of 32.
-// sym: only tiles with tm >= tn are computed and mirrored (C symmetric by construction, e.g. X (F X), D = 2 Co^T Co).
-__global__ __launch_bounds__(BlasTNCfg::NT) void k_blas_gemm_tn(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
-                                                                int64_t ldb, double *__restrict__ C, int64_t ldc, int kchunks,
-                                                                double alpha, int n_tn)
+// C[m][n] = alpha * sum_k A[k][m] B[k][n]   (both operands k-major); M, N multiples of the tile edge (32; 64 for the
+// 8-wave form used on large products: half the operand traffic per flop, see Sp2Cfg64), K a multiple of 32.
+typedef GemmCfg<2, 1, 2, 4, 32> BlasTN64Cfg;     // 64 x 64 tile, 8 waves of 32 x 16
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void k_blas_gemm_tn(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                                          int64_t ldb, double *__restrict__ C, int64_t ldc, int kchunks,
+                                                          double alpha, int n_tn)
 {
-    using Cfg = BlasTNCfg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tm = blockIdx.x / n_tn, tn = blockIdx.x % n_tn;
-    double4_t acc[1][1];
-    acc[0][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_tn_core<Cfg, false, 0, 2>(A + tm * 32, lda, B + tn * 32, ldb, kchunks, acc, smem);
-    const int col = tn * 32 + tile_col<Cfg>(0);
+    double4_t acc[Cfg::WM][Cfg::WN];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) C[(int64_t)(tm * 32 + tile_row<Cfg>(0, j)) * ldc + col] = alpha * acc[0][0][j];
+    for (int m = 0; m < Cfg::WM; ++m)
+#pragma unroll
+        for (int n = 0; n < Cfg::WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_tn_core<Cfg, false, 0, 2>(A + tm * Cfg::TM, lda, B + tn * Cfg::TN, ldb, kchunks, acc, smem);
+#pragma unroll
+    for (int m = 0; m < Cfg::WM; ++m)
+#pragma unroll
+        for (int n = 0; n < Cfg::WN; ++n) {
+            const int col = tn * Cfg::TN + tile_col<Cfg>(n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) C[(int64_t)(tm * Cfg::TM + tile_row<Cfg>(m, j)) * ldc + col] = alpha * acc[m][n][j];
+        }
 }
 
 // C[m][n] = sum_k A[m][k] B[n][k]   (both operands k-contiguous); M, N multiples of 32, K of 16.
@@ -136,20 +145,25 @@ __global__ __launch_bounds__(256) void k_lowdin_prepare(const double *__restrict
 __global__ __launch_bounds__(64) void k_lowdin_info(const double *__restrict__ part0, int n0, const double *__restrict__ part, int ntile,
                                                     int iterations, double *__restrict__ info)
 {
-    if (threadIdx.x != 0) return;
+    __shared__ double res[64];
+    const int t = threadIdx.x;
+    // lane t sums the tiles of step t (and every 64th partial of ||I - G||^2), each in a fixed order
+    double r = 0.0;
+    if (t < iterations)
+        for (int k = 0; k < ntile; ++k) r += part[(int64_t)t * ntile + k];
+    res[t] = (t < iterations) ? 2.0 * sqrt(r) : 0.0;
     double s = 0.0;
-    for (int i = 0; i < n0; ++i) s += part0[i];
-    info[0] = sqrt(s);
+    for (int i = t; i < n0; i += 64) s += part0[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    __syncthreads();
+    if (t != 0) return;
     int used = 0;
-    double last = 0.0;
-    for (int k = 0; k < iterations; ++k) {
-        double r = 0.0;
-        for (int t = 0; t < ntile; ++t) r += part[(int64_t)k * ntile + t];
-        last = 2.0 * sqrt(r);
-        if (!used && last < 2e-7) used = k + 1;
-    }
+    for (int k = 0; k < iterations; ++k)
+        if (!used && res[k] < 2e-7) used = k + 1;
+    info[0] = sqrt(s);
     info[1] = (double)used;
-    info[2] = last;
+    info[2] = res[iterations - 1];
     info[3] = (double)iterations;
 }
 

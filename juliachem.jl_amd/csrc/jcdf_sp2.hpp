@@ -28,9 +28,10 @@
 namespace jcdf {
 
 typedef GemmCfg<1, 1, 2, 2, 32> Sp2Cfg;          // 32 x 32 tile, 4 waves of 16 x 16, 32 k rows per LDS stage
-typedef GemmCfg<2, 2, 2, 2, 32> Sp2Cfg64;        // 64 x 64 tile, 4 waves of 32 x 32: half the operand traffic per flop.  From n ~ 960
-                                                 // on (>= 120 lower tiles) the 32 x 32 form is bound by the L2 (n = 1280: 820 workgroups
-                                                 // x 655 KB of operands per squaring, 59 us)
+typedef GemmCfg<2, 1, 2, 4, 32> Sp2Cfg64;        // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD: one stages while the other multiplies): half the
+                                                 // operand traffic per flop.  From n ~ 960 on (>= 120 lower tiles) the 32 x 32 form is bound by
+                                                 // the L2 (n = 1280: 820 workgroups x 655 KB of operands per squaring, 59 us; 64 x 64 with 4 waves
+                                                 // of 32 x 32, one per SIMD: 61 us — nothing hides the staging; one tile per CU is 36 us of MFMA)
 constexpr int SP2_T64_MIN_NP = 960;
 constexpr int SP2_PAD = 64;                      // matrices are padded to a multiple of this
 constexpr int SP2_PART = 8448;                   // partial-sum slots per parity: padded rows (first launch) or lower tiles
@@ -133,12 +134,13 @@ __global__ __launch_bounds__(256) void k_sp2_init(const double *__restrict__ F, 
 // (every workgroup sums them in the same order and so takes the same decision).
 struct Sp2Decision { int branch, phase_next, done_next; double tx, idem; };   // branch 0: X^2, 1: 2X - X^2
 
-__device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx, double t2, int n_occ, double (*red)[256])
+template <int NT>
+__device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx, double t2, int n_occ, double (*red)[NT])
 {
     red[0][threadIdx.x] = tx;
     red[1][threadIdx.x] = t2;
     __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
+    for (int h = NT / 2; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) {
             red[0][threadIdx.x] += red[0][threadIdx.x + h];
             red[1][threadIdx.x] += red[1][threadIdx.x + h];
@@ -182,21 +184,27 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
                                                        double *Xb_w, int64_t ld, int n_occ, int chunks, double *partials,
                                                        int npart0, int ntri, Sp2State *state, int k)
 {
-    constexpr int TS = Cfg::TM, WM = Cfg::WM, WN = Cfg::WN;
-    static_assert(Cfg::TM == Cfg::TN && Cfg::NT == 256, "square tiles, 4 waves");
+    constexpr int TS = Cfg::TM, WM = Cfg::WM, WN = Cfg::WN, NT = Cfg::NT;
+    static_assert(Cfg::TM == Cfg::TN && (NT & (NT - 1)) == 0, "square tiles, power-of-two workgroup");
     extern __shared__ __align__(16) double smem[];
-    __shared__ double red[2][256];
+    __shared__ double red[2][NT];
     const double *X = (k & 1) ? Xb : Xa;
     double *Xn = (k & 1) ? Xa_w : Xb_w;
     const double *pin = partials + (int64_t)(k & 1) * 2 * SP2_PART;
     double *pout = partials + (int64_t)((k + 1) & 1) * 2 * SP2_PART;
+    // Workgroups are dealt to the 8 XCDs round-robin; tile = (b % 8) * ceil(ntri / 8) + b / 8 gives every XCD a contiguous
+    // run of the row-major tile list, i.e. a few tile rows whose operand column blocks it keeps in its own L2 (with
+    // tile = b every XCD streamed nearly all of X per squaring).  The grid is 8 * ceil(ntri / 8): surplus blocks leave.
+    const int per_xcd = (ntri + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= ntri) return;
     int ti, tj;
-    sp2_tile(blockIdx.x, ti, tj);
+    sp2_tile(tile, ti, tj);
     // state, partial sums and this thread's own X elements: issued before the operand stream, used after it
     const Sp2State st = state[k & 1];
     const int np_in = (k == 0) ? npart0 : ntri;
     double tx = 0.0, t2 = 0.0;
-    for (int p = threadIdx.x; p < np_in; p += 256) {
+    for (int p = threadIdx.x; p < np_in; p += NT) {
         const double2_t v = *reinterpret_cast<const double2_t *>(pin + 2 * p);
         tx += v[0];
         t2 += v[1];
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
             for (int j = 0; j < 4; ++j)
                 x[m][n][j] = X[(int64_t)(ti * TS + tile_row<Cfg>(m, j)) * ld + tj * TS + tile_col<Cfg>(n)];
     if (st.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) state[(k + 1) & 1] = st;
+        if (tile == 0 && threadIdx.x == 0) state[(k + 1) & 1] = st;
         return;
     }
     double4_t acc[WM][WN];
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
 #pragma unroll
         for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
     gemm_tn_core<Cfg, false, 0, 2>(X + ti * TS, ld, X + tj * TS, ld, chunks, acc, smem);
-    const Sp2Decision d = sp2_decide(st, tx, t2, n_occ, red);
+    const Sp2Decision d = sp2_decide<NT>(st, tx, t2, n_occ, red);
     double (*T)[TS + 1] = reinterpret_cast<double (*)[TS + 1]>(smem);      // the GEMM stages are free now (sp2_decide ends on a barrier)
     double ptr = 0.0, pfro = 0.0;
 #pragma unroll
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
     if (ti != tj) {
         __syncthreads();
         // mirrored tile (tj, ti): row c, 4 consecutive columns per thread and pass
-        for (int e = threadIdx.x; e < TS * TS / 4; e += 256) {
+        for (int e = threadIdx.x; e < TS * TS / 4; e += NT) {
             const int c = e / (TS / 4), rr = (e % (TS / 4)) * 4;
             double *dst = Xn + (int64_t)(tj * TS + c) * ld + ti * TS + rr;
             *reinterpret_cast<double2_t *>(dst) = double2_t{T[c][rr], T[c][rr + 1]};
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
     red[0][threadIdx.x] = ptr;
     red[1][threadIdx.x] = pfro;
     __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
+    for (int h = NT / 2; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) {
             red[0][threadIdx.x] += red[0][threadIdx.x + h];
             red[1][threadIdx.x] += red[1][threadIdx.x + h];
@@ -259,8 +267,8 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *reinterpret_cast<double2_t *>(pout + 2 * blockIdx.x) = double2_t{red[0][0], red[1][0]};
-        if (blockIdx.x == 0) {
+        *reinterpret_cast<double2_t *>(pout + 2 * tile) = double2_t{red[0][0], red[1][0]};
+        if (tile == 0) {
             Sp2State nx = st;
             nx.cur = (k + 1) & 1;
             nx.phase = d.phase_next;
