@@ -67,22 +67,54 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+PMC_RECORD = os.path.join("profiles", "r03_pmc_traffic.json")
+STEP_RECORD = os.path.join("profiles", "r03_step_kernels.json")
+
+
+def checked_record(rel, shape=None):
+    """A committed profile record, only if it was measured on THIS kernel source (and shape): (record, None) or (None, why)."""
+    f = os.path.join(ROOT, rel)
+    if not os.path.exists(f):
+        return None, "%s missing" % rel
+    try:
+        rec = json.load(open(f))
+    except Exception as e:
+        return None, "%s unreadable: %r" % (rel, e)
+    if rec.get("csrc_sha256_16") != csrc_hash():
+        return None, "%s was measured on other kernel sources (hash mismatch): re-run tools/collect_round_profiles.sh" % rel
+    if shape is not None and list(rec.get("shape", [])) != list(shape):
+        return None, "%s holds shape %s" % (rel, rec.get("shape"))
+    return rec, None
+
+
+def pmc_kernel(kernel, shape, world):
+    """Per-launch PMC figures of `kernel` from the committed passes (separate rocprofv3 --pmc runs of tools/prof_fock.py,
+    tools/pmc_passes.sh): HBM bytes = 2 FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md), MFMA-busy
+    fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD), LDS bank-conflict share."""
+    if world != 1:
+        return None, "PMC records are single-GPU"
+    rec, why = checked_record(PMC_RECORD, shape)
+    if rec is None:
+        return None, why
+    k = rec.get(kernel)
+    if not k:
+        return None, "%s has no entry %s" % (PMC_RECORD, kernel)
+    out = {"kernel_name": k.get("kernel_name"), "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "source": PMC_RECORD}
+    if k.get("mfma_busy_cycles") and k.get("grbm_gui_active"):
+        out["mfma_busy_frac"] = k["mfma_busy_cycles"] / (k["grbm_gui_active"] / 8.0 * 1024.0)
+    if k.get("lds_bank_conflict") is not None and k.get("lds_idx_active"):
+        out["lds_bank_conflict_frac"] = k["lds_bank_conflict"] / k["lds_idx_active"]
+    return out, None
+
+
 def pmc_traffic(kernel, shape, world):
     """HBM bytes per launch of `kernel` from the committed PMC passes (separate rocprofv3 --pmc runs,
     tools/pmc_passes.sh; (2 FETCH_SIZE + WRITE_SIZE), the gfx950 correction of MI355X_MICROARCH.md) — only if the
     record was taken on THIS kernel source and THIS shape; otherwise null."""
-    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if world != 1 or not os.path.exists(tf):
-        return None, "no PMC record for this run (multi-GPU or file missing)"
-    try:
-        rec = json.load(open(tf))
-        if rec.get("csrc_sha256_16") != csrc_hash():
-            return None, "profiles/r02_pmc_traffic.json was measured on other kernel sources (hash mismatch): re-run tools/pmc_passes.sh"
-        if list(rec.get("shape", [])) != list(shape):
-            return None, "profiles/r02_pmc_traffic.json holds shape %s" % (rec.get("shape"),)
-        return rec[kernel]["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_fock.py; kernel %s, shape and csrc hash checked)" % rec[kernel].get("kernel_name", kernel)
-    except Exception as e:
-        return None, "profiles/r02_pmc_traffic.json unreadable: %r" % (e,)
+    k, why = pmc_kernel(kernel, shape, world)
+    if k is None:
+        return None, why
+    return k["hbm_bytes_per_launch"], "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_fock.py; kernel %s, shape and csrc hash checked)" % (PMC_RECORD, k["kernel_name"])
 
 
 def cpu_baseline(N, Q, o, budget_s=12.0):
@@ -239,14 +271,15 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     fb.close()
     ms = elapsed / steps * 1e3
     Ql = R
-    out = {"value": steps / elapsed, "unit": "SCF iterations/s", "ms_per_step": ms, "steps": steps,
+    out = {"value": steps / elapsed, "unit": "SCF iterations/s", "ms_per_step": ms, "steps": steps, "n_gpus_measured": world,
            "fock_build_ms": fock_ms, "allreduce_ms": coll_ms, "replicated_ms": ms - fock_ms - coll_ms,
            "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in kstats.items()},
            "kept_pair_fraction": P / float(N * N), "aux_rows_rank0": Ql, "device_GB_rank0": nbytes / 1e9,
            "fock_build_useful_tflops": fock_useful_flops(N, Q, o, P) / (fock_ms * 1e-3) / 1e12,
            "fock_build_tflops_dense_formula": fock_alg_flops(N, Q, o) / (fock_ms * 1e-3) / 1e12,
            "setup_s": t_setup, "eigensolver": rep, "density_solver": scf.density_solver,
-           "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks}
+           "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries}
+    out["projected_8gpu"] = projected_8gpu(out, 8.0 * N * N)
     return out
 
 
@@ -293,6 +326,22 @@ def launch_ranks(args, argv):
         sys.stderr.write("bench.py: the %d-rank child printed %d JSON lines (expected 1)\n" % (args.gpus, lines))
         rc = 3
     return rc
+
+
+XGMI_ALLREDUCE_GBS = 7 * 153.0 / 2.0      # ring all-reduce over 7 xGMI links of ~153 GB/s: ~2 (n-1)/n x bytes over the per-GPU link sum; rough
+
+
+def projected_8gpu(line, nbytes):
+    """PROJECTION, not a measurement: 8-GPU time of an SCF iteration from the parts measured on THIS run's ranks — the
+    Fock build shards over the aux index (per-rank time = whole-job Fock-build time / 8), the replicated part does not
+    shard, and the N x N all-reduce is priced at the xGMI ring rate.  ratio = 1-GPU-equivalent time / projected time."""
+    n = line.get("n_gpus_measured", 1)
+    fock_all = line["fock_build_ms"] * n                       # per-rank Fock build x ranks = the whole job's
+    t1 = fock_all + line["replicated_ms"]
+    ar = 2.0 * 7.0 / 8.0 * nbytes / (XGMI_ALLREDUCE_GBS * 1e9) * 1e3 + 0.03
+    t8 = fock_all / 8.0 + line["replicated_ms"] + ar
+    return {"ms_per_step": t8, "speedup_over_1gpu": t1 / t8, "fock_build_ms": fock_all / 8.0, "replicated_ms": line["replicated_ms"],
+            "allreduce_ms_assumed": ar, "note": "projection from measured parts (Amdahl): (F + R) / (F / 8 + R + all-reduce)"}
 
 
 def main(argv=None):
@@ -383,6 +432,16 @@ def main(argv=None):
         j_alone.append([ks["seconds"] for ks in fb.h.kernel_stats() if ks["name"] == "k_coulomb_J"][0])
     fb.h.set_overlap(True)
     j_alone_s = float(np.median(j_alone))
+    # also outside the timed region (the events would sit on the timed stream): the two stages of the replicated eigensolve,
+    # device events around them over 5 more iterations of the same loop
+    sytrd_ms = stedc_ms = None
+    if args.density_solver == "eigh" and scf.eigh.ok:
+        scf.eigh.timing = True
+        for _ in range(5):
+            scf.step()
+        torch.cuda.synchronize(dev)
+        sytrd_ms, stedc_ms = scf.eigh.stage_ms()
+        scf.eigh.timing = False
     # also outside the timed region: the same SCF with the optional spectral-projection density solver (no eigensolve
     # per iteration) — reported beside, never as `value`
     alt = None
@@ -395,8 +454,10 @@ def main(argv=None):
                "replicated_ms": alt_s / args.steps * 1e3 - alt_fock_ms - alt_coll,
                "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in alt_k.items()}, "sp2_steps": scf2.sp2_steps, "sp2_fallbacks": scf2.sp2_fallbacks,
                "energy_minus_eigh": scf2.trail[-1][1] - scf.trail[-1][1],
+               "sp2_basis_retries": scf2.sp2_basis_retries,
                "note": "optional scf flag density_solver=sp2: occupied-space projector by matrix squarings (jcdf_sp2_device) instead "
-                       "of the per-iteration eigensolve; same energies; not the default, not `value`"}
+                       "of the per-iteration eigensolve, basis by Newton-Schulz (jcdf_lowdin_rows_device): every product on the "
+                       "library's own cores; same energies; not the default, not `value`"}
     elapsed = max_over_ranks(elapsed, world, dev)
     solver_report = scf.solver_report()
     fb.close()
@@ -424,6 +485,19 @@ def main(argv=None):
         w_alg = w["alg_flops"]                  # algorithmic flops of ONE launch (this rank's aux shard)
         achieved = w_alg / w_avg / 1e12
         traffic, traffic_src = pmc_traffic("k_exchange_W", (N, Q, o), world)
+        step_rec, step_why = checked_record(STEP_RECORD, (N, Q, o)) if world == 1 else (None, "single-GPU record")
+        k_pmc, k_why = pmc_kernel("k_exchange_K64", (N, Q, o), world)
+        w_pmc, _ = pmc_kernel("k_exchange_W", (N, Q, o), world)
+        kk = kstats["k_exchange_K"]
+        k_avg = kk["seconds"] / kk["n"]
+        k_useful = Q * o * N * (N + 1.0) / world                                  # this rank's shard
+        longest = None
+        if sytrd_ms is not None:
+            longest = {"kernel": "k_sytrd_onehop" if N <= 1000 else "k_sytrd_lower", "role": "replicated eigensolve, tridiagonalisation + Q (caller side, SCF.jl:1083)",
+                       "ms": sytrd_ms, "us_per_column": sytrd_ms * 1e3 / N, "share_of_ms_per_step": sytrd_ms / ms,
+                       "bound": "latency: one chip-wide hand-off per column; not on a flop or byte roofline",
+                       "flops": 4.0 / 3.0 * N ** 3 * 2.0, "frac_fp64_peak": 4.0 / 3.0 * N ** 3 * 2.0 / (sytrd_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                       "stedc_ms": stedc_ms, "measured": "device events around the launch over 5 iterations after the timed loop"}
         out = {
             "metric": "SCF iterations/sec (DF-RHF, C20H42/cc-pVDZ shape); Fock-build TFLOP/s in fock_build_useful_tflops / fock_build_tflops_dense_formula",
             "value": args.steps / elapsed, "unit": "SCF iterations/s", "n_gpus": world, "steps": args.steps,
@@ -439,10 +513,13 @@ def main(argv=None):
             "fock_build_ms": fock_ms,
             "allreduce_ms": coll_ms,
             "replicated_ms": ms - fock_ms - coll_ms,          # DIIS + damping + X F X + eigensolve + density + energy (per rank, not sharded)
-            "vendor_kernels_per_step": 0,                     # default path: every GEMM / GEMV of a step runs on the library's own cores
-            "vendor_kernels_note": "X F X, S D F, (X U)^T, D = 2 Co^T Co, U = Q Z: jcdf_gemm_tn/nt_device; DIIS history: jcdf_diis_*_device; "
-                                   "torch launches left in a step are copies / fills / one axpy. The optional sp2 solver (alt) still "
-                                   "issues 4 thin rocBLAS products per step",
+            # launches of ONE timed step by family, from the committed rocprofv3 kernel trace of this bench — only if that
+            # record was taken on these kernel sources; otherwise null with the reason (never a constant)
+            "vendor_kernels_per_step": step_rec.get("vendor_kernels_per_step") if step_rec else None,
+            "launches_per_step": step_rec.get("launches_per_step") if step_rec else None,
+            "small_launch_ms_per_step": step_rec.get("small_launch_ms_per_step") if step_rec else None,
+            "step_kernels_source": STEP_RECORD + " (rocprofv3 --kernel-trace of bench.py, tools/collect_round_profiles.sh; csrc hash checked)"
+                                   if step_rec else step_why,
             # useful = what must be executed (K symmetric, W on the kept pairs); dense_formula = SURVEY 8d's F_alg (K counted twice over)
             "fock_build_useful_tflops": f_use / (fock_ms * 1e-3) / 1e12,
             "fock_build_useful_pct_fp64_mfma_peak": 100.0 * f_use / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
@@ -457,10 +534,20 @@ def main(argv=None):
                          "launch_ms": w_avg * 1e3, "alg_flops_per_launch": w_alg,
                          "executed_flops_per_launch": w["flops"], "executed_tflops": w["flops"] / w_avg / 1e12,
                          "alg_hbm_GBs": w["alg_bytes"] / w_avg / 1e9,
+                         "mfma_busy_frac_pmc": w_pmc.get("mfma_busy_frac") if w_pmc else None,
+                         # north_star: "MFMA utilisation on the K-build GEMMs": the exchange-K SYRK of the same build
+                         "k_build": {"kernel": "k_exchange_K64", "launch_ms": k_avg * 1e3, "useful_flops_per_launch": k_useful,
+                                     "useful_tflops": k_useful / k_avg / 1e12, "frac_useful": k_useful / k_avg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                     "executed_tflops": kk["flops"] / k_avg / 1e12, "frac_executed": kk["flops"] / k_avg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                     "mfma_busy_frac_pmc": k_pmc.get("mfma_busy_frac") if k_pmc else None,
+                                     "lds_bank_conflict_frac_pmc": k_pmc.get("lds_bank_conflict_frac") if k_pmc else None,
+                                     "pmc_source": k_pmc["source"] if k_pmc else k_why,
+                                     "note": "in the timed steps K runs beside the HBM-bound J pass (kernels_ms)"},
                          "hbm_stream": {"kernel": "k_coulomb_J", "stand_alone_ms": j_alone_s * 1e3,
                                         "GBs": kstats["k_coulomb_J"]["alg_bytes"] / j_alone_s / 1e9,
                                         "peak_GBs": HBM_PEAK_GBS,
                                         "note": "stand-alone launch after the timed loop; in the timed steps J overlaps K (kernels_ms)"}},
+            "longest_kernel": longest,
             "scaling_w50": w50,
         }
         if world == 1 and not args.no_real:
@@ -486,17 +573,30 @@ def real_molecule():
         from juliachem_jl_amd.synthetic import n_alkane
         from juliachem_jl_amd import rhf
         b = json.load(open(os.path.join(ROOT, "tests", "golden", "s22_10_benzene_methane_631g2dfp_jkfit.json")))
+        flags = {"dele": 1e-6, "rmsd": 1e-6, "niter": 50, "df_use_adaptive": False}
         t0 = time.perf_counter()
-        res = rhf.run(n_alkane(20), b["charges"], b["basis"], b["aux_basis"],
-                      {"dele": 1e-6, "rmsd": 1e-6, "niter": 50, "df_use_adaptive": False})
+        res = rhf.run(n_alkane(20), b["charges"], b["basis"], b["aux_basis"], flags)
         wall = time.perf_counter() - t0
         it = res["Iteration Times"]
         ks = {k["name"]: k["seconds"] * 1e3 for k in res["Kernel Stats"]}
-        return {"molecule": "n-C20H42, 6-31G(2df,p) / cc-pVTZ-JKFIT, N=%d" % res["Overlap"].shape[0], "converged": bool(res["Converged?"]),
-                "iterations": int(res["Iterations"]), "energy": float(res["Energy"]), "wall_s": wall,
-                "ms_per_iteration_median": float(np.median(it[1:]) * 1e3), "ms_per_iteration_first": float(it[0] * 1e3),
-                "last_fock_build_kernels_ms": ks, "device_GB": res["Device Bytes"] / 1e9,
-                "kept_pair_fraction": float(res["Timings"].non_timing_data.get("screened_indices_count", 0)) / res["Overlap"].shape[0] ** 2}
+        out = {"molecule": "n-C20H42, 6-31G(2df,p) / cc-pVTZ-JKFIT, N=%d" % res["Overlap"].shape[0], "converged": bool(res["Converged?"]),
+               "iterations": int(res["Iterations"]), "energy": float(res["Energy"]), "wall_s": wall,
+               "ms_per_iteration_median": float(np.median(it[1:]) * 1e3), "ms_per_iteration_first": float(it[0] * 1e3),
+               "last_fock_build_kernels_ms": ks, "device_GB": res["Device Bytes"] / 1e9,
+               "kept_pair_fraction": float(res["Timings"].non_timing_data.get("screened_indices_count", 0)) / res["Overlap"].shape[0] ** 2}
+        # the same run with the reference's block-screened exchange (scf flag df_exchange_screen, ScreenedDF.jl:431-447,459-545;
+        # off by default there and here): K blocks without a kept pair are not computed
+        res2 = rhf.run(n_alkane(20), b["charges"], b["basis"], b["aux_basis"], dict(flags, df_exchange_screen=True))
+        ks2 = {k["name"]: k["seconds"] * 1e3 for k in res2["Kernel Stats"]}
+        kf = {k["name"]: k["flops"] for k in res["Kernel Stats"]}
+        kf2 = {k["name"]: k["flops"] for k in res2["Kernel Stats"]}
+        out["exchange_screen"] = {"df_exchange_screen": True, "n_blocks": int(res2["Timings"].non_timing_data.get("df_exchange_screen_blocks", 0)),
+                                  "k_exchange_K_ms": ks2.get("k_exchange_K"), "k_exchange_K_ms_unscreened": ks.get("k_exchange_K"),
+                                  "k_blocks_computed_fraction": kf2.get("k_exchange_K", 0.0) / max(kf.get("k_exchange_K", 1.0), 1.0),
+                                  "converged": bool(res2["Converged?"]), "iterations": int(res2["Iterations"]),
+                                  "energy_minus_unscreened": float(res2["Energy"]) - float(res["Energy"]),
+                                  "ms_per_iteration_median": float(np.median(res2["Iteration Times"][1:]) * 1e3)}
+        return out
     except Exception as e:                                   # informational object: never fail the bench line for it
         return {"error": repr(e)}
 

@@ -27,6 +27,7 @@ constexpr int TILE_P = 128;     // p-tile of the K kernel == padding unit of Np
 constexpr int TILE_Q = 128;     // aux-index tile of the W kernel
 typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
 typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((address_space(3))) const volatile double lds_cvdouble_t;   // an LDS read the compiler may not merge with its neighbour
 
 // ---------------------------------------------------------------------------
 // C_occ (N x o, column-major, reference layout DensityFitting.jl:49) -> Cpad, Cv.
@@ -554,9 +555,12 @@ __global__ __launch_bounds__(256, 2) void k_exchange_K64(const double *__restric
         for (int ks = 0; ks < KC / 4; ++ks) {
             double a[WM], bb[WN];
 #pragma unroll
-            for (int m = 0; m < WM; ++m) a[m] = As[m * 16 * KC + koff[ks]];
+            // volatile: keeps these as eight ds_read_b64 (64-bank mode, 2 LDS cycles each, conflict-free with the swizzle above).
+            // Merged into ds_read2st64_b64 by the compiler they are banked modulo 32 in groups of 16 lanes: rows r and r + 1
+            // collide (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE) and a pair costs 16 cycles instead of 4.
+            for (int m = 0; m < WM; ++m) a[m] = *(lds_cvdouble_t *)(As + m * 16 * KC + koff[ks]);
 #pragma unroll
-            for (int n = 0; n < WN; ++n) bb[n] = Bs[n * 16 * KC + koff[ks]];
+            for (int n = 0; n < WN; ++n) bb[n] = *(lds_cvdouble_t *)(Bs + n * 16 * KC + koff[ks]);
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll

@@ -35,6 +35,8 @@ class DeviceEigh:
         self.U_padded = None
         self.ok = False
         self.calls = self.fallbacks = 0
+        self.timing = False            # True: device events around the tridiagonalisation and the tridiagonal solver of every call
+        self.stage_events = []         # [(e0, e1, e2)] per call while `timing`; read with stage_ms()
         try:
             tl = os.path.join(os.path.dirname(torch.__file__), "lib")
             self.rb = C.CDLL(os.path.join(tl, "librocblas.so"))
@@ -106,8 +108,10 @@ class DeviceEigh:
             return self._two_stage(Fp, st, p)
         if self.q_replay:
             return self._one_stage_replay(Fp, st, p)
+        ev = self._stamp(None)
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
                                           p(self.Q) if self.with_q else None, p(self.work), self.wb)
+        ev = self._stamp(ev)
         own_gemm = self.with_q and self.own_stedc
         if rc == 0 and self.own_stedc:
             zt, ldz = (self.Zt, self.npad) if own_gemm else (self.Cm, n)
@@ -116,6 +120,7 @@ class DeviceEigh:
         elif rc == 0:
             rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
                                           p(self.info))
+        ev = self._stamp(ev)
         if rc == 0 and own_gemm:
             # U[m][j] = sum_k Q[m][k] Z[k][j] = sum_k Qp[m][k] Zt[j][k]: the NT core; U comes back zero padded (npad x npad)
             self.Qp[:n, :n].copy_(self.Q)
@@ -137,6 +142,27 @@ class DeviceEigh:
             return torch.linalg.eigh(Fp)
         # column-major eigenvector matrix == transpose of the row-major view
         return self.D, self.Cm.T
+
+    def _stamp(self, ev):
+        """timing only: one more device event on the current stream (ev = None starts a call's record)"""
+        if not self.timing:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        if ev is None:
+            ev = []
+            self.stage_events.append(ev)
+        ev.append(e)
+        return ev
+
+    def stage_ms(self):
+        """(tridiagonalisation ms, tridiagonal solver ms) averaged over the calls recorded while `timing`; clears the record.
+        Call after a device synchronise."""
+        recs = [r for r in self.stage_events if len(r) == 3]
+        self.stage_events = []
+        if not recs:
+            return None, None
+        return (sum(r[0].elapsed_time(r[1]) for r in recs) / len(recs), sum(r[1].elapsed_time(r[2]) for r in recs) / len(recs))
 
     def _two_stage(self, Fp, st, p):
         n, npad = self.n, self.npad

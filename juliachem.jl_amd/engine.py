@@ -71,21 +71,66 @@ def _all_reduce(dist, t, op=None) -> None:
         dist.all_reduce(t, **kw)
 
 
-def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int, dist, T_own, alloc, push) -> None:
-    """One-time B formation across ranks (reference: GPUDF.jl:918-997, host-staged
-    MPI.Send/Recv!).  Every rank owns the three-centre integrals of its own aux rows;
-    block s is broadcast from its owner and offered to `push(s0, s1, block)`; a rank r
-    only accumulates blocks with rows_s <= rows_r (L^-1 is lower triangular), which
-    `push` decides.  `alloc(n)` returns an empty receive buffer of n doubles.
+def _p2p(dist, ops) -> None:
+    """a batch of sends / receives ((kind, tensor, peer) triples) as ONE group (RCCL: ncclGroupStart/End, so the transfers
+    to different peers run over their own xGMI links at the same time); device tensors under gloo are staged through the host"""
+    if not ops:
+        return
+    staged = []
+    reqs = []
+    for kind, t, peer in ops:
+        buf = t
+        if _staged(dist, t):
+            buf = t.cpu() if kind == "send" else torch.empty(t.shape, dtype=t.dtype)
+            if kind == "recv":
+                staged.append((t, buf))
+        reqs.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer))
+    for w in dist.batch_isend_irecv(reqs):
+        w.wait()
+    for t, buf in staged:
+        t.copy_(buf)
+
+
+def exchange_three_center_blocks(ranges: Sequence[range], rank: int, world: int, dist, T_own, alloc, push,
+                                 block: Optional[int] = None, stats: Optional[dict] = None) -> None:
+    """One-time B formation across ranks (reference: GPUDF.jl:918-997, host-staged MPI.Send/Recv! of every block to every
+    rank).  Every rank owns the three-centre integrals of its own aux rows, `T_own` = the (rows, P) column-major block
+    (flat: aux index fastest).  B[rows_r] = sum_s L^-1[rows_r, rows_s] T[rows_s] and L^-1 is lower triangular, so block s
+    travels ONLY to the ranks r > s — point-to-point, the lower triangle of the all-to-all — and is offered to
+    `push(s0, s1, chunk)` there; rank s pushes its own block itself.  `block`: at most this many aux rows travel (and are
+    held in the receive buffer) at a time; `alloc(n)` returns a receive buffer of n doubles, allocated once.
+    `stats` (optional dict) counts doubles sent / received and the largest receive buffer.
     Backend-agnostic (RCCL on device tensors, gloo on CPU tensors in the tests)."""
-    P = T_own.numel() // len(ranges[rank])
+    R_own = len(ranges[rank])
+    P = T_own.numel() // R_own
+    if stats is not None:
+        stats.update(sent=0, received=0, recv_buffer=0)
+    step_max = max((min(len(r), block) if block else len(r)) for r in ranges)
+    buf = alloc(step_max * P) if (world > 1 and rank > 0) else None
+    if stats is not None and buf is not None:
+        stats["recv_buffer"] = int(buf.numel())
     for s, rows in enumerate(ranges):
-        if world == 1:
-            blk = T_own
-        else:
-            blk = T_own if s == rank else alloc(len(rows) * P)
-            _broadcast(dist, blk, s)
-        push(rows.start, rows.stop, blk)
+        R = len(rows)
+        if s == rank:
+            push(rows.start, rows.stop, T_own)
+        if world == 1 or rank < s:
+            continue
+        step = min(R, block) if block else R
+        for a0 in range(0, R, step):
+            a1 = min(R, a0 + step)
+            if rank == s:
+                if s == world - 1:
+                    break                                            # the last block has no receiver
+                chunk = T_own if (a0 == 0 and a1 == R) else T_own.view(P, R)[:, a0:a1].contiguous().view(-1)
+                _p2p(dist, [("send", chunk, r) for r in range(s + 1, world)])
+                if stats is not None:
+                    stats["sent"] += int(chunk.numel()) * (world - 1 - s)
+            else:
+                part = buf[:(a1 - a0) * P]
+                _p2p(dist, [("recv", part, s)])
+                push(rows.start + a0, rows.start + a1, part)
+                if stats is not None:
+                    stats["received"] += int(part.numel())
 
 
 def allreduce_fock(F, world: int, dist):
@@ -136,14 +181,20 @@ class DeviceFockBuilder:
         if s0 < self.rows.stop:
             self.h.push_three_center_device(s0, s1, T_dev.data_ptr())
 
-    def exchange_three_center(self, T_own: torch.Tensor) -> None:
-        """One-time B formation across ranks (GPUDF.jl:918-997): every rank owns the
-        three-centre integrals of its own aux rows; block s is broadcast from its
-        owner over RCCL and accumulated by every rank r >= s (L^-1 lower triangular)."""
+    def exchange_three_center(self, T_own: torch.Tensor, block: Optional[int] = None) -> dict:
+        """One-time B formation across ranks (GPUDF.jl:918-997): every rank owns the three-centre integrals of its own aux
+        rows; block s goes point-to-point over RCCL to the ranks r > s only (L^-1 is lower triangular) in pieces of at most
+        `block` aux rows (default: 2 GiB of receive buffer) and is accumulated there.  Returns the traffic counters."""
+        P = T_own.numel() // len(self.rows)
+        if block is None:
+            block = max(16, ((1 << 28) // max(P, 1)) // 16 * 16)
+        stats: dict = {}
         exchange_three_center_blocks(
             self.ranges, self.rank, self.world, self.dist, T_own,
-            lambda n: torch.empty(n, dtype=torch.float64, device=self.device), self.push_three_center_device)
+            lambda n: torch.empty(n, dtype=torch.float64, device=self.device), self.push_three_center_device,
+            block=block, stats=stats)
         torch.cuda.synchronize(self.device)
+        return stats
 
     # ---- per iteration -----------------------------------------------------------
     def build(self, C_occ_dev: torch.Tensor) -> torch.Tensor:

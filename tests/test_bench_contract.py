@@ -34,7 +34,15 @@ def test_bench_prints_the_contract_line():
     for k in ("fock_build_useful_tflops", "fock_build_useful_pct_fp64_mfma_peak", "fock_build_tflops_dense_formula",
               "fock_build_pct_fp64_mfma_peak_dense_formula", "replicated_ms", "allreduce_ms", "fock_build_ms", "vendor_kernels_per_step"):
         assert k in d, k
-    assert d["vendor_kernels_per_step"] == 0
+    # launches per step by family: a hash-checked rocprofv3 record of this very source, or null with the reason — never a constant
+    assert "step_kernels_source" in d and (d["vendor_kernels_per_step"] is None or d["vendor_kernels_per_step"] == 0)
+    assert (d["vendor_kernels_per_step"] is None) == ("mismatch" in d["step_kernels_source"] or "missing" in d["step_kernels_source"])
+    # the longest kernel of the step is named with its share (it is not the roofline kernel) and the K build has its own entry
+    lk = d["longest_kernel"]
+    assert lk["kernel"].startswith("k_sytrd") and 0.2 < lk["share_of_ms_per_step"] < 0.7 and 1.0 < lk["us_per_column"] < 20.0
+    kb = rf["k_build"]
+    assert kb["kernel"] == "k_exchange_K64" and 0.3 < kb["frac_useful"] < kb["frac_executed"] < 1.0
+    assert "mfma_busy_frac_pmc" in kb and "pmc_source" in kb
     assert "fock_build_tflops" not in d and d["fock_build_useful_tflops"] < d["fock_build_tflops_dense_formula"]
     assert d["allreduce_ms"] == 0.0 and abs(d["replicated_ms"] + d["fock_build_ms"] - d["ms_per_step"]) < 1e-9
     # the strong-scaling workload of north_star ((H2O)50 shape) measured in the same run, never `value`
@@ -46,8 +54,15 @@ def test_bench_prints_the_contract_line():
     assert 0.11 < w50["screened_13pct"]["kept_pair_fraction"] < 0.16 and w50["dense_map"]["kept_pair_fraction"] == 1.0
     assert w50["screened_13pct"]["device_GB_rank0"] < 0.4 * w50["dense_map"]["device_GB_rank0"]
     assert w50["screened_13pct"]["kernels_ms"]["k_exchange_W"] < 0.3 * w50["dense_map"]["kernels_ms"]["k_exchange_W"]
+    for kind in ("screened_13pct", "dense_map", "screened_13pct_sp2"):
+        pj = w50[kind]["projected_8gpu"]
+        assert "projection" in pj["note"] and 1.0 < pj["speedup_over_1gpu"] < 8.0
+        assert abs(pj["ms_per_step"] - (pj["fock_build_ms"] + pj["replicated_ms"] + pj["allreduce_ms_assumed"])) < 1e-9
     # a real molecule through the same path beside the synthetic fixed point
     assert d["real_molecule"].get("converged") is True, d["real_molecule"]
+    xs = d["real_molecule"]["exchange_screen"]
+    assert xs["converged"] and xs["k_blocks_computed_fraction"] < 0.9 and xs["k_exchange_K_ms"] < xs["k_exchange_K_ms_unscreened"]
+    assert abs(xs["energy_minus_unscreened"]) < 1e-5                  # the screened K blocks hold no pair above the Schwarz threshold
     # the optional spectral-projection density solver is reported beside, on the same problem, with the same energy
     assert d["density_solver"]["name"] == "eigh"
     assert d["alt"]["density_solver"] == "sp2" and d["alt"]["value"] > 50.0 and abs(d["alt"]["energy_minus_eigh"]) < 1e-6

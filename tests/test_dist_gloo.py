@@ -1,6 +1,6 @@
 """world_size-2 (and 3) CPU tests of the N > 1 path with the gloo backend: the aux
-shard rule, the one-time B-formation exchange (broadcast of T row blocks, lower-
-triangular skip) and the single N x N all-reduce, driven through the SAME helper
+shard rule, the one-time B-formation exchange (point-to-point, block s only to the ranks
+behind it: the lower triangle; bytes per rank asserted) and the single N x N all-reduce, driven through the SAME helper
 functions the GPU engine uses (juliachem_jl_amd.engine), with the oracle standing
 in for the per-shard device arithmetic (no GPU in this container)."""
 import os
@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, Q, o, out):
+def _worker(rank, world, port, N, Q, o, out, block=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,13 +43,28 @@ def _worker(rank, world, port, N, Q, o, out):
             if s0 >= rows.stop:
                 return                               # Linv[rows, s0:s1] == 0
             pushed.append((s0, s1))
-            Tb = blk.numpy().reshape(s1 - s0, N * N)
+            Tb = blk.numpy().reshape(N * N, s1 - s0).T          # the device layout: (rows, P) column-major
             B_local[:] += Linv[rows.start:rows.stop, s0:s1] @ Tb
 
-        T_own = torch.from_numpy(np.ascontiguousarray(T[rows.start:rows.stop]).reshape(-1))
-        exchange_three_center_blocks(ranges, rank, world, dist, T_own,
-                                     lambda n: torch.empty(n, dtype=torch.float64), push)
-        assert pushed == [(r.start, r.stop) for r in ranges[:rank + 1]]
+        T_own = torch.from_numpy(np.ascontiguousarray(T[rows.start:rows.stop].T).reshape(-1))
+        stats = {}
+        allocs = []
+
+        def alloc(n):
+            allocs.append(n)
+            return torch.empty(n, dtype=torch.float64)
+        exchange_three_center_blocks(ranges, rank, world, dist, T_own, alloc, push, block=block, stats=stats)
+        # the lower triangle of the exchange: rank r receives exactly the blocks s < r (in pieces of <= block rows), sends its
+        # own block to the ranks behind it, holds ONE receive buffer of one piece
+        P = N * N
+        step = lambda r: min(len(r), block) if block else len(r)
+        assert stats["received"] == P * sum(len(r) for r in ranges[:rank])
+        assert stats["sent"] == P * len(rows) * (world - 1 - rank)
+        assert len(allocs) == (1 if rank > 0 else 0) and stats["recv_buffer"] == (P * max(step(r) for r in ranges) if rank > 0 else 0)
+        want = []
+        for r in ranges[:rank]:
+            want += [(a, min(r.stop, a + step(r))) for a in range(r.start, r.stop, step(r))]
+        assert sorted(pushed) == sorted(want + [(rows.start, rows.stop)])
         Bref = orc.calculate_B(s.J2c, s.T, rows).reshape(len(rows), N * N)
         assert np.allclose(B_local, Bref, rtol=0, atol=1e-12 * np.abs(Bref).max())
         part = orc.df_rhf_fock_build_BLAS(B_local.reshape(len(rows), N, N), s.C[:, :o])
@@ -63,12 +78,12 @@ def _worker(rank, world, port, N, Q, o, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_fock_build_gloo(world):
+@pytest.mark.parametrize("world,block", [(2, None), (3, None), (3, 5)])
+def test_sharded_fock_build_gloo(world, block):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 23, 40, 4, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 23, 40, 4, out, block)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
