@@ -180,6 +180,10 @@ int32_t jcdf_fock_build_finish(jcdf_handle *h, double *F_out, jcdf_timings *t);
  * `stream` (a hipStream_t; NULL = the handle's stream, see jcdf_set_stream) and is
  * NOT synchronised on return, so the caller can chain an RCCL all-reduce of d_F. */
 int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_F, void *stream);
+/* The same with leading dimensions: orbital i of d_C_occ starts at d_C_occ + ldc * i, column p of d_F at d_F + ldf * p
+ * (ldc, ldf >= N) — a device-resident caller that keeps its matrices zero padded for its own GEMMs passes them as they are
+ * (no repacking kernels between the eigensolver, the Fock build and the DIIS products).  Only the N x N part of d_F is written. */
+int32_t jcdf_fock_build_device_ld(jcdf_handle *h, const double *d_C_occ, int64_t ldc, double *d_F, int64_t ldf, void *stream);
 /* The Coulomb pass (streams half of B, no MFMA) and the exchange K pass (MFMA, W out of L2) both depend only on
  * the W pass: by default J is enqueued on an internal side stream and runs BESIDE K (forked and joined with events
  * on the build's stream; 3.3 -> 3.1 ms per build on the C20H42 shape).  overlap_jk = 0 runs them one after the
@@ -216,12 +220,13 @@ int64_t jcdf_sytrd_workspace_bytes(int64_t n);
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                           double *d_TAU, void *d_work, int64_t work_bytes);
 /* Same, and additionally d_Q (n x n, row-major == the transpose in column-major) receives the
- * orthogonal matrix Q = H_0 H_1 ... of A = Q T Q^T, accumulated inside the same kernel while the
+ * orthogonal matrix Q = H_0 H_1 ... of A = Q T Q^T (row stride ldq >= n, so that it can be written straight into a zero
+ * padded GEMM operand), accumulated inside the same kernel while the
  * reflectors travel between workgroups, so the eigenvectors of A are ONE GEMM Q*Z away (instead of
  * LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
  * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above). */
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
-                            double *d_TAU, double *d_Q, void *d_work, int64_t work_bytes);
+                            double *d_TAU, double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
 /* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
  * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
@@ -291,6 +296,13 @@ int32_t jcdf_diis_push_device(void *stream, int64_t n, int64_t ld, const double 
 int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t len, const double *d_e_hist, double *d_dots,
                               double *d_work /* 64 * nd doubles */);
 int32_t jcdf_diis_mix_device(void *stream, int32_t nd, int64_t n, int64_t ld, const double *d_f_hist, const double *d_coef, double *d_F);
+/* The whole DIIS + damping part of one SCF iteration (SCF.jl:472-505) as ONE call / four launches: push (e = T^T - T and F into
+ * slot `head` of the histories), the new row of Pulay dot products (partial sums in d_work, 64 * nd doubles), the bordered
+ * system with n_use vectors (solve != 0; as jcdf_diis_device, consuming the partial sums directly), and
+ * d_F = (1 - x) d_F_old + x sum_s coef[s] F_s (x = 1: no damping, d_F_old may be NULL; without solve and damping d_F is left as it is). */
+int32_t jcdf_diis_step_device(void *stream, int32_t nd, int32_t head, int32_t n_use, int32_t solve, int64_t n, int64_t ld, const double *d_T,
+                              double *d_F, double *d_e_hist, double *d_f_hist, double *d_Bmat, double *d_coef, int32_t *d_flag, double *d_work,
+                              const double *d_F_old, double x);
 
 /* ---- introspection ------------------------------------------------------------ */
 /* Device bytes held (reference: get_gpu_data_size_dense_MB, DenseGPUDF.jl:305-319). */

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "jcdf_fock_build_begin": (C.c_int32, [_P, _P]),
     "jcdf_fock_build_finish": (C.c_int32, [_P, _P, C.POINTER(jcdf_timings)]),
     "jcdf_fock_build_device": (C.c_int32, [_P, _P, _P, _P]),
+    "jcdf_fock_build_device_ld": (C.c_int32, [_P, _P, _I64, _P, _I64, _P]),
     "jcdf_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "jcdf_synchronize": (C.c_int32, [_P, C.POINTER(jcdf_timings)]),
     "jcdf_get_V": (C.c_int32, [_P, _P]),
@@ -69,7 +70,7 @@ PROTOTYPES = {
     "jcdf_device_potrf_trtri": (C.c_int32, [C.c_int32, _P, _I64]),
     "jcdf_sytrd_workspace_bytes": (_I64, [_I64]),
     "jcdf_sytrd_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
-    "jcdf_sytrd_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64]),
+    "jcdf_sytrd_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64]),
     "jcdf_sytrd_max_n": (_I64, [C.c_int32]),
     "jcdf_diis_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "jcdf_stedc_workspace_bytes": (_I64, [_I64]),
@@ -84,6 +85,7 @@ PROTOTYPES = {
     "jcdf_diis_push_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P]),
     "jcdf_diis_dots_device": (C.c_int32, [_P, C.c_int32, C.c_int32, _I64, _P, _P, _P]),
     "jcdf_diis_mix_device": (C.c_int32, [_P, C.c_int32, _I64, _I64, _P, _P, _P]),
+    "jcdf_diis_step_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double]),
     "jcdf_device_bytes": (_I64, [_P]),
     "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),
     "jcdf_kernel_stats_total": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),

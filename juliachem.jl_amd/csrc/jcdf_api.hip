@@ -341,7 +341,7 @@ void fold_last_build(jcdf_handle *h, bool wait)
     h->unfolded = false;
 }
 
-int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t st)
+int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, int64_t ldf, hipStream_t st)
 {
     fold_last_build(h, false);
     const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o, P = (double)h->P;
@@ -351,7 +351,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
     {
         KernelRec &r = rec_begin(h, k++, "k_prep_C", st, ok);
         const int64_t tot = h->Np * h->opad;
-        hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, (int)h->N,
+        hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, ldc, (int)h->N,
                            (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles * h->WVMw, h->dCpad, h->dCv);
         r.alg_bytes = 8.0 * N * o;
         ok(hipEventRecord(r.e1, st));
@@ -418,7 +418,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, double *dF, hipStream_t s
         KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st, ok);
         hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
                            st, h->dJ, h->dCmap, h->dKslab, h->S, h->nblk64, h->dKblk, h->dBscr, h->xs_width, h->xs_nb,
-                           h->have_H ? h->dH : nullptr, (int)h->N, dF);
+                           h->have_H ? h->dH : nullptr, (int)h->N, dF, ldf);
         r.alg_bytes = 8.0 * N * N * (h->have_H ? 2.0 : 1.0);
         ok(hipEventRecord(r.e1, st));
     }
@@ -745,7 +745,7 @@ hipError_t ensure_device_attributes()
 // ============================================================================
 extern "C" {
 
-int32_t jcdf_abi_version(void) { return 1000; }
+int32_t jcdf_abi_version(void) { return 1001; }
 
 const char *jcdf_last_error(const jcdf_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1300,7 +1300,18 @@ int32_t jcdf_fock_build_device(jcdf_handle *h, const double *d_C_occ, double *d_
     JCDF_HIP(h, hipSetDevice(h->device));
     if (h->stage_doubles) release_stage(h);
     h->timed_host_copy = false;
-    return enqueue_fock(h, d_C_occ, d_F, stream ? (hipStream_t)stream : h->stream);
+    return enqueue_fock(h, d_C_occ, h->N, d_F, h->N, stream ? (hipStream_t)stream : h->stream);
+}
+
+int32_t jcdf_fock_build_device_ld(jcdf_handle *h, const double *d_C_occ, int64_t ldc, double *d_F, int64_t ldf, void *stream)
+{
+    if (!h) return JCDF_ERR_INVALID;
+    if (!h->configured || !h->have_B) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device_ld: B not set");
+    if (!d_C_occ || !d_F || ldc < h->N || ldf < h->N) return fail(h, JCDF_ERR_INVALID, "jcdf_fock_build_device_ld: NULL pointer / leading dimension < N");
+    JCDF_HIP(h, hipSetDevice(h->device));
+    if (h->stage_doubles) release_stage(h);
+    h->timed_host_copy = false;
+    return enqueue_fock(h, d_C_occ, ldc, d_F, ldf, stream ? (hipStream_t)stream : h->stream);
 }
 
 int32_t jcdf_set_overlap(jcdf_handle *h, int32_t overlap_jk)
@@ -1345,7 +1356,7 @@ int32_t jcdf_fock_build_begin(jcdf_handle *h, const double *C_occ)
     JCDF_HIP(h, hipEventRecord(h->ev_h2d, h->stream));
     // pageable host memory: the copy has left the caller's buffer when this returns
     JCDF_HIP(h, hipMemcpyAsync(h->dC, C_occ, (size_t)(h->N * h->o) * 8, hipMemcpyHostToDevice, h->stream));
-    return enqueue_fock(h, h->dC, h->dF, h->stream);
+    return enqueue_fock(h, h->dC, h->N, h->dF, h->N, h->stream);
 }
 
 int32_t jcdf_fock_build_finish(jcdf_handle *h, double *F_out, jcdf_timings *t)
@@ -1432,9 +1443,9 @@ int64_t jcdf_sytrd_workspace_bytes(int64_t n)
 }
 
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
-                            double *d_Q, void *d_work, int64_t work_bytes)
+                            double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes)
 {
-    if (n <= 0 || !d_A || lda < n || !d_D || !d_E || !d_TAU || !d_work || work_bytes < jcdf_sytrd_workspace_bytes(n))
+    if (n <= 0 || !d_A || lda < n || !d_D || !d_E || !d_TAU || !d_work || work_bytes < jcdf_sytrd_workspace_bytes(n) || (d_Q && ldq < n))
         return JCDF_ERR_INVALID;
     size_t lds = 0;
     const int G = sytrd_groups(n, d_Q != nullptr, &lds);
@@ -1459,7 +1470,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         if (hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) \
             return JCDF_ERR_HIP;                                                                                            \
         hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
-                           d_TAU, vg, yg, hg, err, d_Q);                                                                    \
+                           d_TAU, vg, yg, hg, err, d_Q, (int)ldq);                                                          \
     } while (0)
         if (n <= 64) JCDF_ONEHOP(2);
         else if (n <= 256) JCDF_ONEHOP(8);
@@ -1472,14 +1483,14 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     if (hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return JCDF_ERR_HIP;
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
-                       hg, err, d_Q);
+                       hg, err, d_Q, (int)ldq);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
                           void *d_work, int64_t work_bytes)
 {
-    return jcdf_sytrd_q_device(stream, n, d_A, lda, d_D, d_E, d_TAU, nullptr, d_work, work_bytes);
+    return jcdf_sytrd_q_device(stream, n, d_A, lda, d_D, d_E, d_TAU, nullptr, 0, d_work, work_bytes);
 }
 
 #ifdef JCDF_DIAGNOSTIC
@@ -2022,6 +2033,26 @@ int32_t jcdf_diis_dots_device(void *stream, int32_t nd, int32_t head, int64_t le
     hipLaunchKernelGGL(k_diis_dots_partial, dim3(DIIS_DOT_PARTS, (unsigned)nd), dim3(256), 0, (hipStream_t)stream, d_e_hist, len, (int)head,
                        d_work);
     hipLaunchKernelGGL(k_diis_dots_final, dim3(1), dim3(64), 0, (hipStream_t)stream, d_work, (int)nd, d_dots);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+}
+
+int32_t jcdf_diis_step_device(void *stream, int32_t nd, int32_t head, int32_t n_use, int32_t solve, int64_t n, int64_t ld, const double *d_T,
+                              double *d_F, double *d_e_hist, double *d_f_hist, double *d_Bmat, double *d_coef, int32_t *d_flag, double *d_work,
+                              const double *d_F_old, double x)
+{
+    if (nd < 1 || nd > 15 || head < 0 || head >= nd || n_use < 1 || n_use > nd || n <= 0 || ld < n || !d_T || !d_F || !d_e_hist || !d_f_hist ||
+        !d_Bmat || !d_coef || !d_flag || !d_work || (x != 1.0 && !d_F_old))
+        return JCDF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t len = n * n;
+    hipLaunchKernelGGL(k_diis_push, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_T, d_F, ld, (int)n, d_e_hist + (int64_t)head * len,
+                       d_f_hist + (int64_t)head * len);
+    hipLaunchKernelGGL(k_diis_dots_partial, dim3(DIIS_DOT_PARTS, (unsigned)nd), dim3(256), 0, st, d_e_hist, len, (int)head, d_work);
+    hipLaunchKernelGGL(k_diis_solve, dim3(1), dim3(64), 0, st, d_Bmat, (const double *)d_work, (int)nd, (int)head, (int)n_use, (int)solve, d_coef, d_flag,
+                       DIIS_DOT_PARTS);
+    if (solve || x != 1.0)
+        hipLaunchKernelGGL(k_diis_mix, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_f_hist, len, (int)nd, d_coef, (int)n, d_F, ld,
+                           x != 1.0 ? d_F_old : nullptr, x);
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 

@@ -209,9 +209,11 @@ __global__ void k_diis_dots_final(const double *__restrict__ part, int nd, doubl
     dots[s_] = s;
 }
 
-// F[r][c] (ld) = sum_s coef[s] F_hist[s][r*n + c]  (slots with coef 0 are skipped: unused history)
+// F[r][c] (ld) = sum_s coef[s] F_hist[s][r*n + c]  (slots with coef 0 are skipped: unused history); with F_old (same ld) and
+// x != 1 the dynamic damping of SCF.jl:504-505 is applied in the same pass: F = (1 - x) F_old + x sum_s ...
 __global__ __launch_bounds__(256) void k_diis_mix(const double *__restrict__ f_hist, int64_t len, int nd, const double *__restrict__ coef,
-                                                  int n, double *__restrict__ F, int64_t ld)
+                                                  int n, double *__restrict__ F, int64_t ld, const double *__restrict__ F_old = nullptr,
+                                                  double x = 1.0)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= len) return;
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(256) void k_diis_mix(const double *__restrict__ f_h
         const double c = coef[k];
         if (c != 0.0) s += c * f_hist[(int64_t)k * len + idx];
     }
-    F[(int64_t)(idx / n) * ld + (idx % n)] = s;
+    const int64_t at = (int64_t)(idx / n) * ld + (idx % n);
+    F[at] = F_old ? (1.0 - x) * F_old[at] + x * s : s;
 }
 
 }  // namespace jcdf

@@ -275,7 +275,7 @@ constexpr int SYTRD_CB = 8;      // local columns processed together (independen
 // the last ~gridDim.x steps have such workgroups at all).
 __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
+                                                     u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
         for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
     if (Qout)
         for (int r = 0; r < nc; ++r)
-            for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * n + i] = qrow[(size_t)r * n + i];
+            for (int i = tid; i < n; i += nthr) Qout[(size_t)(g + r * G) * ldq + i] = qrow[(size_t)r * n + i];
 }
 
 // ---- the same, two buffers polled together (one round trip): pairs of both, + optional heartbeat ---------------
@@ -539,7 +539,7 @@ __device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *ds
 template <int NR>
 __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                       double *__restrict__ E, double *__restrict__ TAU,
-                                                      u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout)
+                                                      u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     if (haveq) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-            if (seg + 32 * r < n) Qout[(size_t)(g + ce * G) * n + seg + 32 * r] = qreg[r];
+            if (seg + 32 * r < n) Qout[(size_t)(g + ce * G) * ldq + seg + 32 * r] = qreg[r];
     }
 }
 
@@ -783,16 +783,23 @@ __global__ __launch_bounds__(256) void k_sytrd_replay_q(const double *__restrict
 // (n+1) x (n+1) system is solved by Gaussian elimination with partial pivoting in LDS (n <= 15).
 // coef[slot] = c (0 for unused slots).  A singular or non-finite system sets flag[0] = 1 and returns the unit vector
 // on the newest entry (no extrapolation this iteration), like the reference's exception path.
+// nparts > 0: dots[s] is first formed from nparts partial sums per slot (dots[s * nparts + k], fixed order) — the
+// k_diis_dots_partial output consumed directly, one launch less per iteration.
 __global__ __launch_bounds__(64) void k_diis_solve(double *__restrict__ Bmat, const double *__restrict__ dots, int nd, int head,
-                                                  int n, int solve, double *__restrict__ coef, int *__restrict__ flag)
+                                                  int n, int solve, double *__restrict__ coef, int *__restrict__ flag, int nparts = 0)
 {
     __shared__ double M[16][17];
     __shared__ double rhs[16];
     __shared__ int piv_row;
     const int tid = threadIdx.x;
     if (tid < nd) {
-        Bmat[(size_t)head * nd + tid] = dots[tid];
-        Bmat[(size_t)tid * nd + head] = dots[tid];
+        double d = 0.0;
+        if (nparts > 0)
+            for (int k = 0; k < nparts; ++k) d += dots[tid * nparts + k];
+        else
+            d = dots[tid];
+        Bmat[(size_t)head * nd + tid] = d;
+        Bmat[(size_t)tid * nd + head] = d;
     }
     __syncthreads();
     if (tid < nd) coef[tid] = (tid == head) ? 1.0 : 0.0;

@@ -36,13 +36,13 @@ typedef __attribute__((address_space(3))) const volatile double lds_cvdouble_t; 
 //   Cv[(((p*n_mt + mt)*WVM + wm)*4 + g)*4WM + 4m + j] = C[p][i = (mt*WVM + wm)*16WM + 16m + 4j + g]
 // i.e. what lane group g = lane>>4 of wave row wm multiplies its accumulators acc[m][.][j] with.
 // ---------------------------------------------------------------------------
-__global__ void k_prep_C(const double *__restrict__ C, int N, int o, int Np, int opad, int WM, int rows_per_p,
+__global__ void k_prep_C(const double *__restrict__ C, int64_t ldc, int N, int o, int Np, int opad, int WM, int rows_per_p,
                          double *__restrict__ Cpad, double *__restrict__ Cv)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Np * opad) return;
     const int q = (int)(idx / opad), i = (int)(idx % opad);
-    const double v = (q < N && i < o) ? C[q + (int64_t)N * i] : 0.0;
+    const double v = (q < N && i < o) ? C[q + ldc * i] : 0.0;
     Cpad[idx] = v;
     if (q >= N || i >= 16 * WM * rows_per_p) return;      // trailing orbitals of the VALU remainder path are not in Cv
     const int wrow = i / (16 * WM), il = i % (16 * WM);       // wrow = mt*WVM + wm < rows_per_p
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_exchange_K64(const double *__restric
 __global__ __launch_bounds__(256) void k_fock_assemble(
     const double *__restrict__ J, const int *__restrict__ cmap, const double *__restrict__ Kslab, int S, int nblk64,
     const int *__restrict__ kblk, const unsigned char *__restrict__ bscr, int bsw, int nbs,
-    const double *__restrict__ H, int N, double *__restrict__ F)
+    const double *__restrict__ H, int N, double *__restrict__ F, int64_t ldf)
 {
     const int q = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -621,8 +621,8 @@ __global__ __launch_bounds__(256) void k_fock_assemble(
     }
     const double v = 2.0 * j - k;
     const int64_t lo = q + (int64_t)N * p, up = p + (int64_t)N * q;
-    F[lo] = v + (H ? H[lo] : 0.0);
-    if (p != q) F[up] = v + (H ? H[up] : 0.0);
+    F[q + ldf * p] = v + (H ? H[lo] : 0.0);
+    if (p != q) F[p + ldf * q] = v + (H ? H[up] : 0.0);
 }
 
 // ---------------------------------------------------------------------------

@@ -449,6 +449,10 @@ class JCDFHandle:
     def fock_build_device(self, d_C_occ: int, d_F: int, stream: int = 0) -> None:
         self._check(self._lib.jcdf_fock_build_device(self._h, d_C_occ, d_F, stream or None))
 
+    def fock_build_device_ld(self, d_C_occ: int, ldc: int, d_F: int, ldf: int, stream: int = 0) -> None:
+        """jcdf_fock_build_device_ld: orbital i at d_C_occ + ldc i, column p of F at d_F + ldf p (zero padded caller matrices)"""
+        self._check(self._lib.jcdf_fock_build_device_ld(self._h, d_C_occ, int(ldc), d_F, int(ldf), stream or None))
+
     def synchronize(self) -> jcdf_timings:
         t = jcdf_timings()
         self._check(self._lib.jcdf_synchronize(self._h, C.byref(t)))

@@ -35,6 +35,7 @@ class DeviceEigh:
         self.U_padded = None
         self.ok = False
         self.calls = self.fallbacks = 0
+        self.scratch = False           # True: __call__ may destroy its argument (no copy of the matrix)
         self.timing = False            # True: device events around the tridiagonalisation and the tridiagonal solver of every call
         self.stage_events = []         # [(e0, e1, e2)] per call while `timing`; read with stage_ms()
         try:
@@ -102,17 +103,23 @@ class DeviceEigh:
         n = self.n
         st = torch.cuda.current_stream(self.device).cuda_stream
         self.rb.rocblas_set_stream(self.handle, C.c_void_p(st))
-        self.A.copy_(Fp)
         p = lambda t: C.c_void_p(t.data_ptr())
-        if self.two_stage:
-            return self._two_stage(Fp, st, p)
-        if self.q_replay:
-            return self._one_stage_replay(Fp, st, p)
-        ev = self._stamp(None)
-        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU),
-                                          p(self.Q) if self.with_q else None, p(self.work), self.wb)
-        ev = self._stamp(ev)
+        if self.two_stage or self.q_replay:
+            self.A.copy_(Fp)
+            return self._two_stage(Fp, st, p) if self.two_stage else self._one_stage_replay(Fp, st, p)
         own_gemm = self.with_q and self.own_stedc
+        # `scratch`: the caller hands over a work matrix it no longer needs (row stride = its leading dimension): tridiagonalised
+        # in place, no copy; Q goes straight into the zero padded operand of the back-transformation GEMM
+        if self.scratch and own_gemm and Fp.stride(1) == 1:
+            A, lda = Fp, Fp.stride(0)
+        else:
+            self.A.copy_(Fp)
+            A, lda = self.A, n
+        ev = self._stamp(None)
+        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(A), lda, p(self.D), p(self.E), p(self.TAU),
+                                          (p(self.Qp) if own_gemm else p(self.Q)) if self.with_q else None, self.npad if own_gemm else n,
+                                          p(self.work), self.wb)
+        ev = self._stamp(ev)
         if rc == 0 and self.own_stedc:
             zt, ldz = (self.Zt, self.npad) if own_gemm else (self.Cm, n)
             rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(zt), ldz, p(self.dc_work),
@@ -123,7 +130,6 @@ class DeviceEigh:
         ev = self._stamp(ev)
         if rc == 0 and own_gemm:
             # U[m][j] = sum_k Q[m][k] Z[k][j] = sum_k Qp[m][k] Zt[j][k]: the NT core; U comes back zero padded (npad x npad)
-            self.Qp[:n, :n].copy_(self.Q)
             rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), self.npad, self.npad, self.npad, p(self.Qp), self.npad, p(self.Zt),
                                               self.npad, p(self.Up), self.npad)
             if rc == 0:
@@ -191,7 +197,7 @@ class DeviceEigh:
     def _one_stage_replay(self, Fp, st, p):
         n, npad = self.n, self.npad
         main = torch.cuda.current_stream(self.device)
-        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU), None, p(self.work), self.wb)
+        rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(self.A), n, p(self.D), p(self.E), p(self.TAU), None, 0, p(self.work), self.wb)
         if rc == 0:
             self.ev_fork.record(main)
             self.side.wait_event(self.ev_fork)

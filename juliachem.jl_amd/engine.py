@@ -212,6 +212,20 @@ class DeviceFockBuilder:
         self._collective_end(ev)
         return out
 
+    def build_ld(self, C_pad: torch.Tensor, F_pad: torch.Tensor) -> torch.Tensor:
+        """The same for a caller that keeps its matrices zero padded: C_pad (>= n_occ rows, row stride ldc >= N: orbital i in
+        row i), F_pad (square, row stride ldf >= N): this rank's partial Fock matrix is written into the N x N corner of
+        F_pad and all-reduced there (the padding is zero on every rank and stays zero) — no repacking launches."""
+        if self.world > 1:
+            ev = self._collective_begin()
+            _broadcast(self.dist, C_pad, 0)
+            self._collective_end(ev)
+        self.h.fock_build_device_ld(C_pad.data_ptr(), C_pad.stride(0), F_pad.data_ptr(), F_pad.stride(0))
+        ev = self._collective_begin()
+        out = allreduce_fock(F_pad, self.world, self.dist)
+        self._collective_end(ev)
+        return out
+
     def _collective_begin(self):
         if not (self.time_collectives and self.world > 1):
             return None
@@ -292,7 +306,12 @@ class DeviceSCF:
         self.Up = torch.zeros((self.Np, self.Np), **self._f64)      # eigenvectors of X F X (columns), padded
         self.Ctp = torch.zeros((self.Np, self.Np), **self._f64)     # (X U)^T: row i = orbital i in the AO basis
         self.Cop = torch.zeros((self.op, self.Np), **self._f64)     # occupied rows of it, zero rows up to a multiple of 32
-        self.Dp = torch.zeros((self.Np, self.Np), **self._f64)
+        # F and D live in two buffers each, used in turn: the buffer that is not written this iteration still holds last
+        # iteration's matrix — F_old of the damping step and D_old of the convergence test — so neither is ever copied
+        self.Fbuf = [torch.zeros((self.Np, self.Np), **self._f64) for _ in range(2)]
+        self.Dbuf = [torch.zeros((self.Np, self.Np), **self._f64) for _ in range(2)]
+        self.fi = self.di = 0
+        self.eigh.scratch = True                  # X F X is a work matrix: tridiagonalised in place
         self.reset()
 
     # ---- plumbing --------------------------------------------------------------------------------------------
@@ -349,13 +368,27 @@ class DeviceSCF:
     def X(self) -> torch.Tensor:
         return self.Xp[:self.N, :self.N]
 
+    @property
+    def Fp_(self) -> torch.Tensor:
+        return self.Fbuf[self.fi]
+
+    @property
+    def Dp(self) -> torch.Tensor:
+        return self.Dbuf[self.di]
+
+    @property
+    def Co_t(self) -> torch.Tensor:
+        """(n_occ, N) contiguous: the occupied orbitals as the plain Fock-build entry takes them"""
+        return self.Cop[:self.n_occ, :self.N].contiguous()
+
     def reset(self) -> None:
         self.sp2_skip = True
-        self.Fp_ = self.Hp.clone()
-        self.Dp.zero_()
-        self.D_old = torch.zeros_like(self.Dp)
+        self.fi = self.di = 0
+        self.Fbuf[0].copy_(self.Hp)
+        self.Fbuf[1].copy_(self.Hp)                                # F_old of the first iteration (SCF.jl:186)
+        self.Dbuf[0].zero_()
+        self.Dbuf[1].zero_()
         self._checked_diag()                                       # "iteration 0", SCF.jl:178-181
-        self.F_old = self.Fp_.clone()
         self.E_old, self.dE, self.B_dim, self.iter = 0.0, 1.0, 1, 1
         # DIIS history: ring buffers on the device (slot of the newest entry = head); the small
         # Pulay matrix is solved on the device and gets ONE new row of dot products per iteration
@@ -387,7 +420,7 @@ class DeviceSCF:
             self._sp2_basis()
             return
         else:
-            self.eps, U = self.eigh(self.Fpr[:N, :N])
+            self.eps, U = self.eigh(self.Fpr[:N, :N])               # (destroys Fpr: eigh.scratch)
             Up = self.eigh.U_padded                                 # the library path leaves U zero padded (Np x Np) already
             if Up is None:
                 self.Up[:N, :N].copy_(U)
@@ -397,7 +430,6 @@ class DeviceSCF:
                 self.Cpt[:o, :N].copy_(Up[:N, :o].t())              # occupied orbitals in the orthogonal basis, (o, N)
             self.Cop[:o].copy_(self.Ctp[:o])
             self.canonical = True
-        self.Co_t = self.Cop[:o, :N].contiguous()                   # (o, N) row-major == (N, o) column-major, for the Fock build
         self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)             # D = 2 Co^T Co (zero rows of Cop add nothing)
 
     def _sp2_basis(self) -> None:
@@ -408,7 +440,6 @@ class DeviceSCF:
         self._gemm_nt(self.Cpt, self.Xp, self.Cop)                  # (o, N): rows = occupied orbitals in the AO basis (X symmetric)
         self.sp2_pivot = self.lowdin.info[1:2]                      # Newton-Schulz steps needed, 0 = no convergence
         self.canonical = False
-        self.Co_t = self.Cop[:o, :N].contiguous()
         self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)
 
     def _checked_diag(self) -> None:
@@ -464,6 +495,44 @@ class DeviceSCF:
             self._checked_diag()                                   # sets C, eps (and D, Co_t: the same space)
             self.Dp.copy_(D)
 
+    def _diis_on_host(self, Fp: torch.Tensor) -> None:
+        """debug path (JCDF_DIIS_HOST=1): history on the device, the Pulay system solved by numpy (one more sync per iteration)"""
+        N, nd = self.N, self.ndiis
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        self._gemm_tn(self.Dp, Fp, self.T1)
+        self._gemm_tn(self.Sp, self.T1, self.T2)
+        self.head = (self.head + 1) % nd
+        self.n_hist = min(self.n_hist + 1, nd)
+        rc = self._lib.jcdf_diis_push_device(self._st(), N, self.Np, p(self.T2), p(Fp), p(self.e_hist[self.head]), p(self.F_hist[self.head]))
+        rc = rc or self._lib.jcdf_diis_dots_device(self._st(), nd, self.head, N * N, p(self.e_hist), p(self.dots_d), p(self.dots_work))
+        if rc != 0:
+            raise RuntimeError("DIIS history kernels failed (status %d)" % rc)
+        dots = self.dots_d.cpu().numpy()
+        self.Bmat[self.head, :] = dots
+        self.Bmat[:, self.head] = dots
+        if self.iter <= 1:
+            return
+        self.B_dim = min(self.B_dim + 1, nd)
+        n = self.B_dim
+        order = [(self.head - k) % nd for k in range(n)]           # newest first, like the reference's vcat
+        Bm = -np.ones((n + 1, n + 1))
+        Bm[:n, :n] = self.Bmat[np.ix_(order, order)]
+        Bm[n, n] = 0.0
+        rhs = np.zeros(n + 1)
+        rhs[n] = -1.0
+        try:
+            c = np.linalg.solve(Bm, rhs)[:n]
+            if not np.all(np.isfinite(c)):
+                raise np.linalg.LinAlgError("non-finite DIIS coefficients")
+            cfull = np.zeros(nd)
+            cfull[order] = c
+            self.coef_d.copy_(torch.as_tensor(cfull, device=self.coef_d.device))
+            rc = self._lib.jcdf_diis_mix_device(self._st(), nd, N, self.Np, p(self.F_hist), p(self.coef_d), p(Fp))
+            if rc != 0:
+                raise RuntimeError("jcdf_diis_mix_device failed (status %d)" % rc)
+        except np.linalg.LinAlgError:                              # "Faulty DIIS!" SCF.jl:493-499
+            self.B_dim = 2
+
     profile = False
 
     def _mark(self, name: str) -> None:
@@ -485,69 +554,34 @@ class DeviceSCF:
                 self.seg = {}
         N = self.N
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        Fb = torch.zeros((self.Np, self.Np), **self._f64) if self.Np != N else None
-        Fnew = self.fb.build(self.Co_t)                            # SCF.jl:463 (N x N, contiguous)
-        if Fb is None:
-            Fp = Fnew.clone()
-        else:
-            Fb[:N, :N].copy_(Fnew)
-            Fp = Fb
+        F_old = self.Fbuf[self.fi]                                 # last iteration's final Fock matrix stays where it is
+        Fp = self.Fbuf[self.fi ^ 1]
+        self.fb.build_ld(self.Cop, Fp)                             # SCF.jl:463: F = H + 2J - K straight into the padded buffer
         self._mark("fock")
-        if self.ndiis > 0:                                         # SCF.jl:472-501
+        x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
+        if self.ndiis > 0 and not self.diis_on_host:               # SCF.jl:472-505: DIIS + damping, four launches
             nd = self.ndiis
             self._gemm_tn(self.Dp, Fp, self.T1)                     # D F
             self._gemm_tn(self.Sp, self.T1, self.T2)                # S D F = (F D S)^T
             self.head = (self.head + 1) % nd
             self.n_hist = min(self.n_hist + 1, nd)
-            rc = self._lib.jcdf_diis_push_device(self._st(), N, self.Np, p(self.T2), p(Fp), p(self.e_hist[self.head]),
-                                                 p(self.F_hist[self.head]))
-            rc = rc or self._lib.jcdf_diis_dots_device(self._st(), nd, self.head, N * N, p(self.e_hist), p(self.dots_d), p(self.dots_work))
-            if rc != 0:
-                raise RuntimeError("DIIS history kernels failed (status %d)" % rc)
             solve = self.iter > 1
-        if self.ndiis > 0 and not self.diis_on_host:               # the Pulay system solved on the device
             if solve:
                 self.B_dim = min(self.B_dim + 1, nd)
-            rc = self._lib.jcdf_diis_device(self._st(), nd, self.head, self.B_dim if solve else 1, 1 if solve else 0,
-                                            p(self.Bmat_d), p(self.dots_d), p(self.coef_d), p(self.diis_flag))
-            if rc == 0 and solve:
-                # sum_k c_k F_k; a faulty system leaves the unit vector on the newest F
-                rc = self._lib.jcdf_diis_mix_device(self._st(), nd, N, self.Np, p(self.F_hist), p(self.coef_d), p(Fp))
+            rc = self._lib.jcdf_diis_step_device(self._st(), nd, self.head, self.B_dim if solve else 1, 1 if solve else 0, N, self.Np,
+                                                 p(self.T2), p(Fp), p(self.e_hist), p(self.F_hist), p(self.Bmat_d), p(self.coef_d),
+                                                 p(self.diis_flag), p(self.dots_work), p(F_old) if x != 1.0 else None, x)
             if rc != 0:
-                raise RuntimeError("jcdf_diis_device / _mix failed (status %d)" % rc)
-        elif self.ndiis > 0:                                       # host solve (JCDF_DIIS_HOST=1): one extra sync per iteration
-            dots = self.dots_d.cpu().numpy()
-            self.Bmat[self.head, :] = dots
-            self.Bmat[:, self.head] = dots
-            if solve:
-                self.B_dim = min(self.B_dim + 1, nd)
-                n = self.B_dim
-                order = [(self.head - k) % nd for k in range(n)]   # newest first, like the reference's vcat
-                Bm = -np.ones((n + 1, n + 1))
-                Bm[:n, :n] = self.Bmat[np.ix_(order, order)]
-                Bm[n, n] = 0.0
-                rhs = np.zeros(n + 1)
-                rhs[n] = -1.0
-                try:
-                    c = np.linalg.solve(Bm, rhs)[:n]
-                    if not np.all(np.isfinite(c)):
-                        raise np.linalg.LinAlgError("non-finite DIIS coefficients")
-                    cfull = np.zeros(nd)
-                    cfull[order] = c
-                    self.coef_d.copy_(torch.as_tensor(cfull, device=self.coef_d.device))
-                    rc = self._lib.jcdf_diis_mix_device(self._st(), nd, N, self.Np, p(self.F_hist), p(self.coef_d), p(Fp))
-                    if rc != 0:
-                        raise RuntimeError("jcdf_diis_mix_device failed (status %d)" % rc)
-                except np.linalg.LinAlgError:                      # "Faulty DIIS!" SCF.jl:493-499
-                    self.B_dim = 2
+                raise RuntimeError("jcdf_diis_step_device failed (status %d)" % rc)
+        else:
+            if self.ndiis > 0:
+                self._diis_on_host(Fp)
+            if x != 1.0:
+                Fp.mul_(x).add_(F_old, alpha=1.0 - x)
         self._mark("diis")
-        x = 1.0 / math.log(50.0 * self.dE, 50.0) if self.dE >= 1.0 else 1.0     # SCF.jl:504
-        if x != 1.0:
-            Fp = (1.0 - x) * self.F_old + x * Fp
-        self.Fp_ = Fp
-        self.F_old = self.Fp_.clone()
-        self.D_old.copy_(self.Dp)
-        D_old = self.D_old
+        self.fi ^= 1                                               # self.Fp_ is the new matrix, the other buffer holds F_old
+        D_old = self.Dbuf[self.di]
+        self.di ^= 1                                               # _diag writes the new density into the other buffer
         self._mark("damp")
         use_sp2 = self.sp2 is not None and not self.sp2_skip
         self._diag(use_sp2)

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export %s" % n
         assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
-    assert _lib.load().jcdf_abi_version() == 1000
+    assert _lib.load().jcdf_abi_version() == 1001
 
 
 def test_library_exports_nothing_but_the_declared_abi():
