@@ -1465,7 +1465,8 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     //  956: 5.86 vs 6.11 ms; at n = 1250 the two-exchange kernel with 512 threads stays ahead: 8.70 vs 8.89 ms)
     const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1000;
     if (onehop && n <= 1000) {
-        const int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
+        int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
+        if (const char *e = diag_env("JCDF_SYTRD_G1")) G1 = std::max(G1, std::min(256, atoi(e)));                 // diagnostic builds: more workgroups
         const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
 #define JCDF_ONEHOP(NR)                                                                                                     \
     do {                                                                                                                    \

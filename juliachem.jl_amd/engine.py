@@ -473,18 +473,21 @@ class DeviceSCF:
             raise RuntimeError("jcdf_scf_tail_device failed (status %d)" % rc)
         if self.fb.world > 1:
             # every rank must take the same decisions (convergence, DIIS reset, fallbacks) or the next collective hangs:
-            # trouble flags are OR-ed over the ranks, everything else is rank 0's record
+            # trouble flags are OR-ed over the ranks, everything else is rank 0's record — ONE small all-reduce (sum): the
+            # other ranks contribute zeros to the record part, every rank its own flags
             rec, dist = self.tail_out, self.fb.dist
-            trouble = torch.zeros(2, dtype=torch.float64, device=rec.device)
-            trouble[0] = (rec[3] != 0).to(torch.float64)
+            buf = torch.zeros(10, dtype=torch.float64, device=rec.device)
+            if self.fb.rank == 0:
+                buf[:8] = rec
+            buf[8] = (rec[3] != 0).to(torch.float64)
             if use_sp2:
                 good = (rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & (rec[6] >= 1.0) & torch.isfinite(rec[0])
-                trouble[1] = (~good).to(torch.float64)
-            _all_reduce(dist, trouble, dist.ReduceOp.MAX)
-            _broadcast(dist, rec, 0)
-            rec[3] = trouble[0]
+                buf[9] = (~good).to(torch.float64)
+            _all_reduce(dist, buf)
+            rec.copy_(buf[:8])
+            rec[3] = buf[8]
             if use_sp2:
-                rec[4] = torch.where(trouble[1] != 0, torch.zeros_like(rec[4]), rec[4])
+                rec[4] = torch.where(buf[9] != 0, torch.zeros_like(rec[4]), rec[4])
         return self.tail_out.cpu().tolist()
 
     def canonical_orbitals(self) -> None:
