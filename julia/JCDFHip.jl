@@ -99,6 +99,11 @@ function setup!(scf_data, jeri_engine_thread_df, jeri_engine_thread, basis_sets,
         rc = ccall((:jcdf_create, libjcdf), Int32, (Ref{Ptr{Cvoid}}, Int32), href, dev - 1)
         rc == 0 || error(unsafe_string(ccall((:jcdf_last_error, libjcdf), Cstring, (Ptr{Cvoid},), C_NULL)))
         h = href[]
+        # scf flag df_exchange_screen (SCFOptions.jl:92-93; ScreenedDF.jl:431-447, 459-545): K blocks of width N / n_blocks
+        # without a kept pair are not computed; n_blocks = df_exchange_n_blocks or the screened mode's default of 10
+        xs_blocks = scf_options.df_screen_exchange ?
+            (scf_options.df_exchange_n_blocks == 0 ? 10 : scf_options.df_exchange_n_blocks) : 0
+        check(h, ccall((:jcdf_set_exchange_screening, libjcdf), Int32, (Ptr{Cvoid}, Int64), h, xs_blocks))
         check(h, ccall((:jcdf_configure, libjcdf), Int32,
                        (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
                        h, N, A, first(rows) - 1, last(rows), occ, P, pq_p, pq_q))
