@@ -46,7 +46,8 @@ inline const char *diag_env(const char *) { return nullptr; }
 
 struct KernelRec {
     const char *name;
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1;       // the two events of the most recent build's set that bracket this kernel
+    int i0, i1;              // their indices in a set
     double flops, alg_flops, alg_bytes;
     double sum_seconds;      // accumulated over the builds folded so far (jcdf_kernel_stats_total)
 };
@@ -95,13 +96,21 @@ struct jcdf_handle {
 
     // timing
     std::vector<KernelRec> recs;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_h2d = nullptr, ev_d2h = nullptr;
+    // Device time stamps of a build: EIGHT events, shared between neighbouring kernels (the end of one is the start of the next;
+    // every record is a barrier packet on the queue, ~5 us of bubble each: 15 records per build cost 70 us, 8 cost half), in
+    // TWO sets used in turn, so that the times of build k are read while build k+1 is already enqueued.
+    //   0 begin = prep_C start | 1 prep_C end = W start | 2 W end | 3 fork = K start = J start | 4 J end (join) | 5 K end |
+    //   6 assemble start (behind the join) | 7 assemble end = end of the build
+    static constexpr int NEV = 8;
+    hipEvent_t evset[2][NEV] = {};
+    int evcur = 0;                      // set of the most recent build
+    bool set_unfolded[2] = {false, false};
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;     // = evset[evcur][0] / [7] of the most recent build
+    hipEvent_t ev_h2d = nullptr, ev_d2h = nullptr;
     hipStream_t side = nullptr;                      // the HBM-bound J pass runs beside the MFMA-bound K pass (overlap_jk)
     bool overlap_jk = true;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timed_host_copy = false;
     bool pending = false;
-    bool unfolded = false;              // the last build's event times are not yet in the accumulators
     int64_t builds_folded = 0;
     double fock_sum_seconds = 0.0;
 };
@@ -171,8 +180,9 @@ void free_all(jcdf_handle *h)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (h->dBscr) { (void)hipFree(h->dBscr); h->dBscr = nullptr; }
     if (h->dStall) { (void)hipFree(h->dStall); h->dStall = nullptr; }
-    for (auto &r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    h->recs.clear();
+    h->recs.clear();                    // (their events belong to h->evset)
+    h->set_unfolded[0] = h->set_unfolded[1] = false;
+    h->pending = false;
     h->bytes = 0;
     h->stage_doubles = 0;
     h->configured = h->have_metric = h->have_B = h->have_H = h->pushed_any = false;
@@ -307,57 +317,64 @@ struct HipAcc {
     void operator()(hipError_t e) { if (first == hipSuccess && e != hipSuccess) first = e; }
 };
 
-KernelRec &rec_begin(jcdf_handle *h, size_t idx, const char *name, hipStream_t st, HipAcc &ok)
+// record slot idx of the build being enqueued: name and the two events of the current set that bracket it
+KernelRec &rec_slot(jcdf_handle *h, size_t idx, const char *name, int e0, int e1)
 {
-    while (h->recs.size() <= idx) {
-        KernelRec r{};
-        ok(hipEventCreate(&r.e0));
-        ok(hipEventCreate(&r.e1));
-        h->recs.push_back(r);
-    }
+    while (h->recs.size() <= idx) h->recs.push_back(KernelRec{});
     KernelRec &r = h->recs[idx];
     r.name = name;
     r.flops = r.alg_flops = r.alg_bytes = 0.0;
-    ok(hipEventRecord(r.e0, st));
+    r.e0 = h->evset[h->evcur][e0];
+    r.e1 = h->evset[h->evcur][e1];
+    r.i0 = e0;
+    r.i1 = e1;
     return r;
 }
 
 double elapsed_s(hipEvent_t a, hipEvent_t b);
 
-// Adds the event times of the last build to the running sums (jcdf_kernel_stats_total) — called before its events are
-// recorded again.  wait = false: only if that build has already finished (never blocks the enqueue path).
-void fold_last_build(jcdf_handle *h, bool wait)
+// Adds the event times of the build recorded in `set` to the running sums (jcdf_kernel_stats_total).  wait = false: only if
+// that build has already finished (never blocks the enqueue path); returns false if it was still running.
+bool fold_set(jcdf_handle *h, int set, bool wait)
 {
-    if (!h->unfolded || h->recs.empty()) return;
+    if (!h->set_unfolded[set] || h->recs.empty()) return true;
+    hipEvent_t *E = h->evset[set];
     if (wait) {
-        if (hipEventSynchronize(h->ev_end) != hipSuccess) return;
-    } else if (hipEventQuery(h->ev_end) != hipSuccess) {
-        h->unfolded = false;                       // still running: this build is left out of the sums
-        return;
+        if (hipEventSynchronize(E[jcdf_handle::NEV - 1]) != hipSuccess) return false;
+    } else if (hipEventQuery(E[jcdf_handle::NEV - 1]) != hipSuccess) {
+        return false;
     }
-    for (auto &r : h->recs) r.sum_seconds += elapsed_s(r.e0, r.e1);
-    h->fock_sum_seconds += elapsed_s(h->ev_begin, h->ev_end);
+    for (auto &r : h->recs) r.sum_seconds += elapsed_s(E[r.i0], E[r.i1]);
+    h->fock_sum_seconds += elapsed_s(E[0], E[jcdf_handle::NEV - 1]);
     h->builds_folded++;
-    h->unfolded = false;
+    h->set_unfolded[set] = false;
+    return true;
 }
 
 int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, int64_t ldf, hipStream_t st)
 {
-    fold_last_build(h, false);
+    // the set this build records into held the build before last: its times are read now at the latest (a build that is
+    // still running when its events are needed again is left out of the sums)
+    const int prev = h->evcur, set = h->evcur ^ 1;
+    if (!fold_set(h, set, false)) h->set_unfolded[set] = false;
+    h->evcur = set;
+    hipEvent_t *E = h->evset[set];
+    h->ev_begin = E[0];
+    h->ev_end = E[jcdf_handle::NEV - 1];
     const double N = (double)h->N, Ql = (double)h->Ql, o = (double)h->o, P = (double)h->P;
     HipAcc ok;
     size_t k = 0;
-    ok(hipEventRecord(h->ev_begin, st));
+    ok(hipEventRecord(E[0], st));
     {
-        KernelRec &r = rec_begin(h, k++, "k_prep_C", st, ok);
+        KernelRec &r = rec_slot(h, k++, "k_prep_C", 0, 1);
         const int64_t tot = h->Np * h->opad;
         hipLaunchKernelGGL(k_prep_C, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dC, ldc, (int)h->N,
                            (int)h->o, (int)h->Np, h->opad, h->WMw, h->n_mtiles * h->WVMw, h->dCpad, h->dCv);
         r.alg_bytes = 8.0 * N * o;
-        ok(hipEventRecord(r.e1, st));
+        ok(hipEventRecord(E[1], st));
     }
     {
-        KernelRec &r = rec_begin(h, k++, "k_exchange_W", st, ok);
+        KernelRec &r = rec_slot(h, k++, "k_exchange_W", 1, 2);
         ok(launch_W(h, st));
         // incl. all padding: orbitals to opad, K_p to whole stages, the aux index to whole 32-column wave tiles (DMA kernel)
         r.flops = 2.0 * (double)h->kcw * (double)h->n_stages *
@@ -366,7 +383,7 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, 
                    (double)h->w_rem * (double)h->n_qt * h->tq);               // MFMA row tiles + the VALU remainder orbitals
         r.alg_flops = 2.0 * Ql * P * o + 2.0 * Ql * N * o;           // the reference's 2 Q P o (+ fused V from W)
         r.alg_bytes = 8.0 * Ql * P + 8.0 * Ql * o * N;               // B read once + W written once
-        ok(hipEventRecord(r.e1, st));
+        ok(hipEventRecord(E[2], st));
     }
     // V from the W kernel's partials: only the Coulomb pass needs it, so it goes in front of J (on J's stream)
     auto run_reduce_V = [&](hipStream_t sv) {
@@ -374,19 +391,18 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, 
         hipLaunchKernelGGL(k_reduce_V, dim3((unsigned)((h->ldq + 31) / 32)), dim3(256), 0, sv, h->dVpart, nparts, h->vld,
                            (int)h->Ql, (int)h->ldq, h->dV);
     };
-    auto run_J = [&](size_t slot, hipStream_t st, bool reduce_first = true) {
-        if (reduce_first) run_reduce_V(st);
-        KernelRec &r = rec_begin(h, slot, "k_coulomb_J", st, ok);
+    // e0 / e1: indices of the events that bracket the launch; the caller records them
+    auto run_J = [&](size_t slot, hipStream_t st, int e0, int e1) {
+        KernelRec &r = rec_slot(h, slot, "k_coulomb_J", e0, e1);
         const int64_t groups = (h->Plow + 4 * J_ROWS - 1) / (4 * J_ROWS);
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)h->num_cu * JCDF_J_BLOCKS_PER_CU));
         hipLaunchKernelGGL(k_coulomb_J, dim3(grid), dim3(256), (size_t)h->ldq * sizeof(double), st, h->dB, h->ldq, h->dV,
                            h->dJrow, h->Plow, h->dJ);
         r.flops = r.alg_flops = 2.0 * Ql * (double)h->Plow;
         r.alg_bytes = 8.0 * Ql * (double)h->Plow;                    // the kept pairs with q >= p, once
-        ok(hipEventRecord(r.e1, st));
     };
-    auto run_K = [&](size_t slot) {
-        KernelRec &r = rec_begin(h, slot, "k_exchange_K", st, ok);
+    auto run_K = [&](size_t slot, int e0, int e1) {
+        KernelRec &r = rec_slot(h, slot, "k_exchange_K", e0, e1);
         const int nwg = (int)(roundup(h->S, 8) * h->ngroups);
         hipLaunchKernelGGL(k_exchange_K64, dim3((unsigned)nwg), dim3(256), K64_SMEM_BYTES, st, h->dWt, h->Wld, h->dKgroups, h->ngroups,
                            h->S, h->KS, h->dKslab, h->nblk64);
@@ -394,41 +410,50 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, 
         r.flops = 2.0 * (double)h->nblk64 * 64.0 * 64.0 * (double)h->S * (double)h->KS;
         r.alg_flops = 2.0 * Ql * o * N * N;                          // dense formula
         r.alg_bytes = 8.0 * Ql * o * N;                              // W read once
-        ok(hipEventRecord(r.e1, st));
     };
     // record slots stay fixed (2 = J, 3 = K) whatever the launch order
     static const bool k_first = [] { const char *e = diag_env("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
     static const int overlap_env = [] { const char *e = diag_env("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
+    run_reduce_V(st);                                  // 13 us alone, 36 us when it has to start beside the K kernel's workgroups
+    ok(hipEventRecord(E[3], st));
     if (overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk) {
-        // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs
-        if (!h->side) {
-            ok(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-            ok(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            ok(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
-        // V's reduction goes in front of the fork: 13 us alone, 36 us when it has to start beside the K kernel's 504 workgroups
-        run_reduce_V(st);
-        ok(hipEventRecord(h->ev_fork, st));
-        ok(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        run_J(2, h->side, false);
-        run_K(3);
-        ok(hipEventRecord(h->ev_join, h->side));
-        ok(hipStreamWaitEvent(st, h->ev_join, 0));
-    } else if (k_first) { run_K(3); run_J(2, st); } else { run_J(2, st); run_K(3); }
+        // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs.
+        // The fork and the join are the timing events themselves.
+        if (!h->side) ok(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        ok(hipStreamWaitEvent(h->side, E[3], 0));
+        run_J(2, h->side, 3, 4);
+        ok(hipEventRecord(E[4], h->side));
+        run_K(3, 3, 5);
+        ok(hipEventRecord(E[5], st));
+        ok(hipStreamWaitEvent(st, E[4], 0));
+    } else if (k_first) {
+        run_K(3, 3, 5);
+        ok(hipEventRecord(E[5], st));
+        run_J(2, st, 5, 4);
+        ok(hipEventRecord(E[4], st));
+    } else {
+        run_J(2, st, 3, 4);
+        ok(hipEventRecord(E[4], st));
+        run_K(3, 4, 5);
+        ok(hipEventRecord(E[5], st));
+    }
+    ok(hipEventRecord(E[6], st));
     k = 4;
     {
-        KernelRec &r = rec_begin(h, k++, "k_fock_assemble", st, ok);
+        KernelRec &r = rec_slot(h, k++, "k_fock_assemble", 6, 7);
         hipLaunchKernelGGL(k_fock_assemble, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->N), dim3(256), 0,
                            st, h->dJ, h->dCmap, h->dKslab, h->S, h->nblk64, h->dKblk, h->dBscr, h->xs_width, h->xs_nb,
                            h->have_H ? h->dH : nullptr, (int)h->N, dF, ldf);
         r.alg_bytes = 8.0 * N * N * (h->have_H ? 2.0 : 1.0);
-        ok(hipEventRecord(r.e1, st));
     }
-    ok(hipEventRecord(h->ev_end, st));
+    ok(hipEventRecord(E[7], st));
     ok(hipGetLastError());
     if (ok.first != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("Fock build enqueue: ") + hipGetErrorString(ok.first));
     h->pending = true;
-    h->unfolded = true;
+    h->set_unfolded[set] = true;
+    // the previous build has normally finished by now (the caller read its result): its times are added up here, behind the
+    // enqueue of this one, not in front of it
+    (void)fold_set(h, prev, false);
     return JCDF_OK;
 }
 
@@ -716,7 +741,8 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_chol_diag, CHOL_DIAG_LDS);
     set((const void *)k_chol_inv_gemm, C64Cfg::SMEM_BYTES);
     set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
-    set((const void *)k_dc_update_mfma, DcCfg::SMEM_BYTES);
+    set((const void *)k_dc_update_mfma<DcCfg>, DcCfg::SMEM_BYTES);
+    set((const void *)k_dc_update_mfma<DcCfg32>, DcCfg32::SMEM_BYTES);
     set((const void *)k_dc_prepare, 64 * 1024);
     set((const void *)k_blas_gemm_tn<BlasTNCfg>, BlasTNCfg::SMEM_BYTES);
     set((const void *)k_blas_gemm_tn<BlasTN64Cfg>, BlasTN64Cfg::SMEM_BYTES);
@@ -787,8 +813,11 @@ int32_t jcdf_create(jcdf_handle **out, int32_t device_id)
     }
     h->stream = h->own_stream;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipEventCreate(&h->ev_begin)) != hipSuccess || (e = hipEventCreate(&h->ev_end)) != hipSuccess ||
-        (e = hipEventCreate(&h->ev_h2d)) != hipSuccess || (e = hipEventCreate(&h->ev_d2h)) != hipSuccess ||
+    for (int a = 0; a < 2 && e == hipSuccess; ++a)
+        for (int b = 0; b < jcdf_handle::NEV && e == hipSuccess; ++b) e = hipEventCreate(&h->evset[a][b]);
+    h->ev_begin = h->evset[0][0];
+    h->ev_end = h->evset[0][jcdf_handle::NEV - 1];
+    if (e != hipSuccess || (e = hipEventCreate(&h->ev_h2d)) != hipSuccess || (e = hipEventCreate(&h->ev_d2h)) != hipSuccess ||
         (e = ensure_device_attributes()) != hipSuccess) {
         g_create_error = std::string("jcdf_create: ") + hipGetErrorString(e);
         jcdf_destroy(h);
@@ -804,12 +833,11 @@ int32_t jcdf_destroy(jcdf_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     free_all(h);
-    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
-    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < jcdf_handle::NEV; ++b)
+            if (h->evset[a][b]) (void)hipEventDestroy(h->evset[a][b]);
     if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
     if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1899,8 +1927,14 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
             }
             if (maxm >= DC_MFMA_MIN) {
                 const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
-                hipLaunchKernelGGL(k_dc_update_mfma, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
-                                   wk.X, wk.Zp, wk.ldx, wk.G);
+                if ((int64_t)tiles * lv.nm < 128) {          // too few 64 x 64 tiles to fill the chip: 32 x 32
+                    const unsigned t32 = (unsigned)(((maxm + 31) / 32) * ((maxm + 31) / 32));
+                    hipLaunchKernelGGL(k_dc_update_mfma<DcCfg32>, dim3(t32, (unsigned)lv.nm), dim3(DcCfg32::NT), DcCfg32::SMEM_BYTES, st, mg,
+                                       wk.K, wk.X, wk.Zp, wk.ldx, wk.G);
+                } else {
+                    hipLaunchKernelGGL(k_dc_update_mfma<DcCfg>, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
+                                       wk.X, wk.Zp, wk.ldx, wk.G);
+                }
             } else {
                 const unsigned tiles = (unsigned)std::min(64, ((maxm + 15) / 16) * ((maxm + 15) / 16));
                 hipLaunchKernelGGL(k_dc_update_simple, dim3(tiles, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.X, wk.Zp, wk.ldx,
@@ -2109,7 +2143,8 @@ int32_t jcdf_kernel_stats_total(jcdf_handle *h, jcdf_kernel_stat *out, int32_t m
                                 int32_t reset)
 {
     if (!h) return 0;
-    fold_last_build(h, true);
+    (void)fold_set(h, h->evcur ^ 1, true);
+    (void)fold_set(h, h->evcur, true);
     int32_t n = 0;
     if (out)
         for (auto &r : h->recs) {

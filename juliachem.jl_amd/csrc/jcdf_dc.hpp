@@ -477,21 +477,26 @@ __global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restr
     dc_update_simple_body(merges, Kin, X, Zp, ldx, Gm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
 
-// MFMA version for the large merges: 64 x 64 output tile per workgroup.  grid: (tiles, merges)
+// MFMA version for the large merges: T x T output tile per workgroup, T = 64 or 32.  grid: (tiles, merges).  The levels
+// near the top have one or two merges: with 64 x 64 tiles a 510-row merge is 64 workgroups on a 256-CU chip, each walking
+// the whole contraction alone (41-49 us); 32 x 32 tiles spread the same product over 256 (k_stedc picks the tile).
 using DcCfg = GemmCfg<2, 2, 2, 2, 16>;
+using DcCfg32 = GemmCfg<1, 1, 2, 2, 16>;
+template <class Cfg>
 __global__ __launch_bounds__(256) void k_dc_update_mfma(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                         const double *__restrict__ X, const double *__restrict__ Zp,
                                                         int64_t ldx, double *__restrict__ Gm)
 {
-    using Cfg = DcCfg;
+    constexpr int T = Cfg::TM;
+    static_assert(Cfg::TM == Cfg::TN, "square tiles");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DcMerge mg = merges[blockIdx.y];
     const int K = Kin[blockIdx.y], m = mg.n1 + mg.n2;
-    const int tj = (K + 63) / 64, tr = (m + 63) / 64;
+    const int tj = (K + T - 1) / T, tr = (m + T - 1) / T;
     const double *Xm = X + (int64_t)mg.xoff * ldx, *Zm = Zp + (int64_t)mg.xoff * ldx;
     double *G = Gm + (int64_t)mg.xoff * ldx;
     for (int tile = blockIdx.x; tile < tj * tr; tile += gridDim.x) {
-        const int j0 = (tile / tr) * 64, r0 = (tile % tr) * 64;
+        const int j0 = (tile / tr) * T, r0 = (tile % tr) * T;
         double4_t acc[Cfg::WM][Cfg::WN];
 #pragma unroll
         for (int a = 0; a < Cfg::WM; ++a)
