@@ -739,6 +739,8 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_metric_apply, GemmNT<MCfg>::SMEM_BYTES);
     set((const void *)k_coulomb_J, 150 * 1024);
     set((const void *)k_chol_diag, CHOL_DIAG_LDS);
+    set((const void *)k_q_tail_reflect, ((SYTD2_TAIL_T - 2) * SYTD2_TAIL_T + SYTD2_TAIL_T) * 8);
+    set((const void *)k_sytd2_tail, SYTD2_TAIL_T * SYTD2_TAIL_T * 8);
     set((const void *)k_chol_inv_gemm, C64Cfg::SMEM_BYTES);
     set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
     set((const void *)k_dc_update_mfma<DcCfg>, DcCfg::SMEM_BYTES);
@@ -1465,11 +1467,25 @@ static int sytrd_groups(int64_t n, bool with_q, size_t *lds_bytes)
     return G;
 }
 
+static int64_t sytrd_granule_bytes(int64_t n)
+{
+    // err word (64 B header) + granule pairs: v 2(n+1), y 2n (+ 512 spare); 16 B per pair
+    return 64 + (int64_t)(2 * (n + 1) + 2 * n + 2 * 256) * 16;
+}
+
+// the trailing SYTD2_TAIL_T columns go to the one-workgroup kernel (n = 130: 0.76 -> 0.57 ms per eigensolve, 256: 1.43 -> 1.06,
+// 510: 2.69 -> 2.49, 1250: 9.54 -> 9.05); a matrix of up to SYTD2_TAIL_T rows goes there whole
+// (diagnostic builds: JCDF_SYTRD_TAIL = smallest n that uses it, 0 = never)
+static bool sytrd_use_tail(int64_t n)
+{
+    static const int64_t min_n = diag_env("JCDF_SYTRD_TAIL") ? atoll(diag_env("JCDF_SYTRD_TAIL")) : 32;
+    return min_n > 0 && n >= std::max<int64_t>(min_n, 3);
+}
+
 int64_t jcdf_sytrd_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    // err word (64 B header) + granule pairs: v 2(n+1), y 2n (+ 512 spare); 16 B per pair
-    return 64 + (int64_t)(2 * (n + 1) + 2 * n + 2 * 256) * 16;
+    return roundup(sytrd_granule_bytes(n), 256);          // the granules (zeroed every call)
 }
 
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,
@@ -1485,13 +1501,29 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     int *err = (int *)(w + 8);
     jcdf::u64 *vg = (jcdf::u64 *)(w + 64), *yg = vg + 2 * (n + 2), *hg = yg + 2 * ((n + 1) & ~(int64_t)1);
     // tags restart at 1 every call: all granules (and the error word) are zeroed first
-    if (hipMemsetAsync(w, 0, (size_t)jcdf_sytrd_workspace_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
+    if (hipMemsetAsync(w, 0, (size_t)sytrd_granule_bytes(n), st) != hipSuccess) return JCDF_ERR_HIP;
+    // the last 128 columns in one workgroup (k_sytd2_tail: ~1.7 us per column instead of one chip-wide hand-off of 4.6-7 us each)
+    const bool tail = sytrd_use_tail(n);
+    const int kstop = tail ? (int)std::max<int64_t>(n - SYTD2_TAIL_T, 0) : (int)n;
+    auto finish = [&]() -> int32_t {
+        if (tail) {
+            if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+            hipLaunchKernelGGL(k_sytd2_tail, dim3(1), dim3(SYTD2_TAIL_NT), (size_t)SYTD2_TAIL_T * SYTD2_TAIL_T * 8, st, d_A, (int)lda, (int)n, kstop,
+                               d_D, d_E, d_TAU);
+            if (d_Q)                                                         // Q[:, kstop:] times the block's reflectors, row-parallel
+                hipLaunchKernelGGL(k_q_tail_reflect, dim3((unsigned)((n + Q_TAIL_ROWS - 1) / Q_TAIL_ROWS)), dim3(Q_TAIL_NT),
+                                   (size_t)((SYTD2_TAIL_T - 2) * SYTD2_TAIL_T + SYTD2_TAIL_T) * 8, st, d_Q, (int)ldq, (int)n, kstop, (int)n - kstop,
+                                   (const double *)d_A, (int)lda, (const double *)d_TAU, kstop == 0 ? 1 : 0);
+        }
+        return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+    };
     // one exchange per column (every workgroup forms the reflector itself) wins while the redundant work is small:
     // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
     static const int onehop_env = diag_env("JCDF_SYTRD_ONEHOP") ? atoi(diag_env("JCDF_SYTRD_ONEHOP")) : -1;
     // (with every poll of a thread in flight at once, sub_two_n, the one-exchange kernel also wins at n = 700: 3.86 vs 3.98 ms and
     //  956: 5.86 vs 6.11 ms; at n = 1250 the two-exchange kernel with 512 threads stays ahead: 8.70 vs 8.89 ms)
     const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1000;
+    if (kstop == 0) return finish();                                     // the whole matrix is the tail (Q starts as the unit matrix there)
     if (onehop && n <= 1000) {
         int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
         if (const char *e = diag_env("JCDF_SYTRD_G1")) G1 = std::max(G1, std::min(256, atoi(e)));                 // diagnostic builds: more workgroups
@@ -1501,7 +1533,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         if (hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) \
             return JCDF_ERR_HIP;                                                                                            \
         hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
-                           d_TAU, vg, yg, hg, err, d_Q, (int)ldq);                                                          \
+                           d_TAU, vg, yg, hg, err, d_Q, (int)ldq, kstop);                                                   \
     } while (0)
         if (n <= 64) JCDF_ONEHOP(2);
         else if (n <= 256) JCDF_ONEHOP(8);
@@ -1509,13 +1541,13 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         else if (n <= 640) JCDF_ONEHOP(20);
         else JCDF_ONEHOP(32);
 #undef JCDF_ONEHOP
-        return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+        return finish();
     }
     if (hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return JCDF_ERR_HIP;
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
-                       hg, err, d_Q, (int)ldq);
-    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
+                       hg, err, d_Q, (int)ldq, kstop);
+    return finish();
 }
 
 int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E, double *d_TAU,

@@ -275,13 +275,16 @@ constexpr int SYTRD_CB = 8;      // local columns processed together (independen
 // the last ~gridDim.x steps have such workgroups at all).
 __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                      double *__restrict__ E, double *__restrict__ TAU,
-                                                     u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq)
+                                                     u64 *vg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq, int kstop)
 {
+    // kstop: columns 0 .. kstop-1 are reduced here (kstop >= n-1: all of them); with kstop < n-1 the kernel leaves the
+    // trailing block A[kstop:, kstop:] with every update applied, for k_sytd2_tail
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int ncol_max = (n + G - 1) / G;
     const int nc = (n - g + G - 1) / G > 0 ? (n - g + G - 1) / G : 0;       // my columns: g, g+G, ...
     const int Ga = n < G ? n : G;                         // workgroups that own columns and take part
+    const int kend = kstop < n - 1 ? kstop : n - 1;
     if (nc == 0) return;                                  // owns nothing; nobody waits for it
     double *slab = lds;                                   // column c (global j = g + c G) at slab + c*n
     double *vs = lds + (size_t)ncol_max * n;
@@ -329,12 +332,12 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
 #ifdef JCDF_SYTRD_PROFILE
     u64 tprof = wall_clock64();
 #endif
-    if (n > 1 && g == 0) {
+    if (n > 1 && kend > 0 && g == 0) {
         double part = 0.0;
         for (int i = 2 + tid; i < n; i += nthr) part += slab[i] * slab[i];
         reflector(0, block_sum(part, red, rs));
     }
-    for (int k = 0; k < n - 1; ++k) {
+    for (int k = 0; k < kend; ++k) {
         const int m = n - k - 1;                          // rows k+1 .. n-1
         const int buf = k & 1;
         const unsigned tag = step_tag(k);
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
         SYTRD_TICK(0);                                    // waited for v
         const double tau = vs[m];
         const int c0 = (k + 1 - g + G - 1) / G;           // first local column with j > k
-        const bool next_owner = (k + 1 < n - 1) && (g == (k + 1) % G);
+        const bool next_owner = (k + 1 < kend) && (g == (k + 1) % G);
 
         {   // tau == 0 (nothing to annihilate) runs the same exchange with y = 0: every slot is rewritten every step
             // ---- y_j = tau * A22[:, j] . v for my columns j > k: 32 lanes per column, SYTRD_CB columns per pass
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
         __syncthreads();
         SYTRD_TICK(3);                                    // rank-2 update (+ reflector when next owner)
     }
-    if (g == (n - 1) % G && tid == 0) D[n - 1] = slab[(size_t)((n - 1) / G) * n + (n - 1)];
+    if (kend == n - 1 && g == (n - 1) % G && tid == 0) D[n - 1] = slab[(size_t)((n - 1) / G) * n + (n - 1)];
     __syncthreads();
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
@@ -539,8 +542,9 @@ __device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *ds
 template <int NR>
 __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                       double *__restrict__ E, double *__restrict__ TAU,
-                                                      u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq)
+                                                      u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq, int kstop)
 {
+    // kstop: as in k_sytrd_lower (columns 0 .. kstop-1 are reduced; kstop < n-1 leaves A[kstop:, kstop:] updated for k_sytd2_tail)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int ncol_max = (n + G - 1) / G;
@@ -633,6 +637,22 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
             }
             break;
         }
+        if (r0 == kstop) {
+            // early stop: column r0 is stored as it is after update k (no reflector), update k goes into my other columns
+            // (no y, nothing sent), and the trailing block is left to the one-workgroup kernel
+            if (mine)
+                for (int i = tid; i < m; i += nthr) own[i] = cs[i];
+            const int c0 = (r0 + 1 - g + G - 1) / G;
+            for (int cbase = c0; cbase < nc; cbase += cpp) {
+                if (cbase + ce < nc) {
+                    const int j = g + (cbase + ce) * G;
+                    double *col = slab + (size_t)(cbase + ce) * n + r0;
+                    const double wj = ws[j - r0], vj = vs[j - r0];
+                    for (int i = seg; i < m; i += 32) col[i] -= vs[i] * wj + ws[i] * vj;
+                }
+            }
+            break;
+        }
         const double alpha = cs[1];
         double tau_next, beta, scale;                     // (rsq / rcp + Newton: ~130 instead of ~270 cycles of dependent fp64 ops)
         house_scalars(alpha, xnorm2, tau_next, beta, scale);
@@ -701,6 +721,244 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (seg + 32 * r < n) Qout[(size_t)(g + ce * G) * ldq + seg + 32 * r] = qreg[r];
+    }
+}
+
+// ---- k_sytd2_tail: the LAST columns of the tridiagonalisation in ONE workgroup -------------------------------------------------
+// The chip-wide kernels above pay one hand-off per column (4.6-7 us) whatever is left of the matrix.  The trailing block
+// A[k0:, k0:] of T = n - k0 <= 128 rows fits the REGISTER FILE of one workgroup: 512 threads x 32 doubles.  Wave w, lane l holds
+// rows w, w + 8, w + 16, ... (16 of them) of the columns l and l + 64 (both triangles, kept symmetric): rows are dealt to the waves
+// cyclically, so the part still to be reduced stays spread over all eight as it shrinks.  The persistent kernel stops at column
+// k0 (kstop) and this kernel finishes the job — LAPACK dsytd2 on the block: D, E, TAU for rows k0 .., reflectors back into A.
+// Per column: the column goes to LDS (as ROW j of the symmetric block: two elements per lane of one wave), its norm in every wave
+// (no block reduction), the reflector's scalars in every thread, y = tau A v as register FMAs + an eight-way sum through LDS, y.v
+// again in every wave, the rank-2 update with w = y - (tau y.v / 2) v folded into the column factor,
+//   A -= v (y + 2 al v)_c^T + y v_c^T,
+// four barriers in all; only vectors travel through LDS (a first version with the block itself in LDS ran 9800 cycles per
+// column, bound by LDS instruction issue), and groups of four registers whose rows are already reduced are skipped, as is the
+// first column of a lane once j has passed 63.  The reflectors are kept in LDS (T x 128 doubles) exactly as they were applied
+// and go to A at the end, LAPACK storage (beta on the sub-diagonal, v below it): scaling the register copy of column j instead
+// would store a v that differs from the applied one (taken from ROW j) by the rounding asymmetry of the two triangles — for a
+// graded matrix enough to cost Q two digits of orthogonality (water / 6-31G(2df,p) core Hamiltonian: 4e-14 instead of 1e-15).
+constexpr int SYTD2_TAIL_T = 128;
+constexpr int SYTD2_TAIL_NT = 512;
+__global__ __launch_bounds__(SYTD2_TAIL_NT) void k_sytd2_tail(double *__restrict__ A, int lda, int n, int k0, double *__restrict__ D,
+                                                             double *__restrict__ E, double *__restrict__ TAU)
+{
+    constexpr int TM = SYTD2_TAIL_T, NW = SYTD2_TAIL_NT / 64, RW = TM / NW;       // 8 waves, RW = 16 rows of a column per thread
+    // vectors in natural order (index = row) and dealt by wave (row i at (i % 8) * 16 + i / 8: a thread's 16 rows are contiguous)
+    __shared__ __attribute__((aligned(16))) double vn[TM], vd[TM], yn[TM], yd[TM], xs[TM], yp[NW][TM];
+    __shared__ double dl[TM], el[TM], tl[TM];            // D, E, TAU of the block: to global memory once, at the end (a global store
+                                                         // in front of a barrier makes the workgroup wait for it)
+    extern __shared__ __attribute__((aligned(16))) double vall[];              // reflector j at vall + j * TM, natural order
+    const int tid = threadIdx.x, T = n - k0, lane = tid & 63, w = tid >> 6;
+    const int c0 = lane, c1 = lane + 64;
+    auto dealt = [](int i) { return (i & (NW - 1)) * RW + (i >> 3); };
+    double a0[RW], a1[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = NW * r + w;
+        a0[r] = (c0 < T && row < T) ? A[(size_t)(k0 + c0) * lda + k0 + row] : 0.0;
+        a1[r] = (c1 < T && row < T) ? A[(size_t)(k0 + c1) * lda + k0 + row] : 0.0;
+    }
+#ifdef JCDF_TAIL_TICKS
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64(), w0 = wall_clock64();
+#define TT(i) { const long long tn = clock64(); tk[i] += tn - tprev; tprev = tn; }
+#else
+#define TT(i)
+#endif
+    TT(0);
+    for (int j = 0; j + 1 < T; ++j) {
+        // ---- row j (= column j) -> LDS: wave j % 8 holds it, register j / 8, two elements per lane
+        if (w == (j & (NW - 1))) {
+            double x0, x1;
+            switch (j >> 3) {
+#define JCDF_ROWSEL(r) case r: x0 = a0[r]; x1 = a1[r]; break;
+                JCDF_ROWSEL(0) JCDF_ROWSEL(1) JCDF_ROWSEL(2) JCDF_ROWSEL(3) JCDF_ROWSEL(4) JCDF_ROWSEL(5) JCDF_ROWSEL(6) JCDF_ROWSEL(7)
+                JCDF_ROWSEL(8) JCDF_ROWSEL(9) JCDF_ROWSEL(10) JCDF_ROWSEL(11) JCDF_ROWSEL(12) JCDF_ROWSEL(13) JCDF_ROWSEL(14)
+#undef JCDF_ROWSEL
+            default: x0 = a0[RW - 1]; x1 = a1[RW - 1]; break;
+            }
+            xs[c0] = x0;
+            xs[c1] = x1;
+        }
+        __syncthreads();
+        TT(1);
+        // (every wave sums the whole column itself, two elements per lane: the same bits everywhere, and no second trip through LDS)
+        const int e0 = 2 * lane, e1 = 2 * lane + 1;
+        const double2_t xp = *reinterpret_cast<const double2_t *>(xs + e0);
+        const double xnorm2 = wave_sum(((e0 >= j + 2 && e0 < T) ? xp.x * xp.x : 0.0) + ((e1 >= j + 2 && e1 < T) ? xp.y * xp.y : 0.0));
+        const double alpha = xs[j + 1], diag = xs[j];
+        double tau, beta, scale;
+        TT(2);
+        house_scalars(alpha, xnorm2, tau, beta, scale);                        // the same scalars in every thread
+        if (w == 0) {
+            double2_t v;
+            v.x = (e0 <= j || e0 >= T) ? 0.0 : ((e0 == j + 1) ? 1.0 : xp.x * scale);
+            v.y = (e1 <= j || e1 >= T) ? 0.0 : ((e1 == j + 1) ? 1.0 : xp.y * scale);
+            *reinterpret_cast<double2_t *>(vn + e0) = v;
+            *reinterpret_cast<double2_t *>(vall + (size_t)j * TM + e0) = v;
+            vd[dealt(e0)] = v.x;
+            vd[dealt(e1)] = v.y;
+            if (tid == 0) {
+                dl[j] = diag;
+                el[j] = beta;
+                tl[j] = tau;
+            }
+        }
+        __syncthreads();
+        TT(3);
+        if (tau != 0.0) {                                                      // (uniform: every thread holds the same tau)
+            const bool both = j < 63;                                          // columns 0 .. 63 are behind j otherwise: v_c = w_c = 0 there
+            // ---- y_c = tau sum_i A[i][c] v_i: my rows from registers, the eight waves' parts through LDS
+            {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int g = 0; g < RW; g += 4) {
+                    if (NW * (g + 3) + w > j) {                                // (wave-uniform) the group's last row is still to be reduced
+                        const double2_t va = *reinterpret_cast<const double2_t *>(vd + w * RW + g);
+                        const double2_t vb = *reinterpret_cast<const double2_t *>(vd + w * RW + g + 2);
+                        s1 += a1[g] * va.x + a1[g + 1] * va.y + a1[g + 2] * vb.x + a1[g + 3] * vb.y;
+                        if (both) s0 += a0[g] * va.x + a0[g + 1] * va.y + a0[g + 2] * vb.x + a0[g + 3] * vb.y;
+                    }
+                }
+                yp[w][c0] = s0;
+                yp[w][c1] = s1;
+            }
+            __syncthreads();
+            TT(4);
+            // y and y.v in every wave (two elements per lane), y to LDS from the first wave: one barrier instead of a block reduction
+            double dot;
+            {
+                double2_t y = {0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    const double2_t p = *reinterpret_cast<const double2_t *>(&yp[q][e0]);
+                    y.x += p.x;
+                    y.y += p.y;
+                }
+                const double2_t vp = *reinterpret_cast<const double2_t *>(vn + e0);
+                y.x = (e0 > j && e0 < T) ? tau * y.x : 0.0;
+                y.y = (e1 > j && e1 < T) ? tau * y.y : 0.0;
+                if (w == 0) {
+                    *reinterpret_cast<double2_t *>(yn + e0) = y;
+                    yd[dealt(e0)] = y.x;
+                    yd[dealt(e1)] = y.y;
+                }
+                dot = wave_sum(y.x * vp.x + y.y * vp.y);
+            }
+            const double al2 = -tau * dot;                                     // 2 al, al = -tau y.v / 2
+            __syncthreads();
+            TT(5);
+            // ---- A -= v w^T + w v^T, w = y + al v: v and y vanish up to row / column j, so the reduced part (and the reflector) stay.
+            //      (The LDS pipe, not its latency, is what these loops wait for: every wave fetches its own 16 v_i and y_i, 1 KB per
+            //      instruction whether the lanes read the same address or not; fetching all of them ahead of the branches was slower.)
+            {
+                const double vc0 = vn[c0], vc1 = vn[c1], wc0 = yn[c0] + al2 * vc0, wc1 = yn[c1] + al2 * vc1;
+#pragma unroll
+                for (int g = 0; g < RW; g += 4) {
+                    if (NW * (g + 3) + w > j) {
+                        const double2_t va = *reinterpret_cast<const double2_t *>(vd + w * RW + g);
+                        const double2_t vb = *reinterpret_cast<const double2_t *>(vd + w * RW + g + 2);
+                        const double2_t ya = *reinterpret_cast<const double2_t *>(yd + w * RW + g);
+                        const double2_t yb = *reinterpret_cast<const double2_t *>(yd + w * RW + g + 2);
+                        a1[g] -= va.x * wc1 + ya.x * vc1;
+                        a1[g + 1] -= va.y * wc1 + ya.y * vc1;
+                        a1[g + 2] -= vb.x * wc1 + yb.x * vc1;
+                        a1[g + 3] -= vb.y * wc1 + yb.y * vc1;
+                        if (both) {
+                            a0[g] -= va.x * wc0 + ya.x * vc0;
+                            a0[g + 1] -= va.y * wc0 + ya.y * vc0;
+                            a0[g + 2] -= vb.x * wc0 + yb.x * vc0;
+                            a0[g + 3] -= vb.y * wc0 + yb.y * vc0;
+                        }
+                    }
+                }
+            }
+        }
+        TT(6);
+        // (no barrier here: xs is rewritten next, and nobody reads it after the barrier that published v; v, yp and y are rewritten
+        //  two barriers further on)
+    }
+#ifdef JCDF_TAIL_TICKS
+    if (tid == 0)
+        printf("tail ticks: load %lld | col->lds %lld norm %lld house+v %lld matvec %lld y,dot %lld update %lld | wall %lld (100 MHz)\n", tk[0], tk[1],
+               tk[2], tk[3], tk[4], tk[5], tk[6], wall_clock64() - w0);
+#endif
+#undef TT
+    if (w == ((T - 1) & (NW - 1))) {                                           // the last diagonal element
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (NW * r + w == T - 1) {
+                if (c0 == T - 1) dl[T - 1] = a0[r];
+                if (c1 == T - 1) dl[T - 1] = a1[r];
+            }
+    }
+    __syncthreads();
+    if (tid < T) {
+        D[k0 + tid] = dl[tid];
+        if (tid + 1 < T) {
+            E[k0 + tid] = el[tid];
+            TAU[k0 + tid] = tl[tid];
+        }
+    }
+    // LAPACK storage of the lower triangle: D on the diagonal, beta on the sub-diagonal, the reflector below it (the upper triangle
+    // of the block keeps what the chip-wide kernel left there: nobody reads it)
+    for (int e = tid; e < T * TM; e += SYTD2_TAIL_NT) {
+        const int c = e / TM, row = e % TM;
+        if (row >= c && row < T)
+            A[(size_t)(k0 + c) * lda + k0 + row] = (row == c) ? dl[c] : ((row == c + 1) ? el[c] : vall[(size_t)c * TM + row]);
+    }
+}
+
+// Q[:, k0 : k0 + T] <- Q[:, k0 : k0 + T] H_k0 H_k0+1 ... (the reflectors k_sytd2_tail left in A, LAPACK storage) for all rows of Q
+// (row-major, leading dimension ldq): every row is e_r^T Q H H ..., independent of the others, so the whole chip takes part.
+// The T - 2 reflectors go to LDS once per workgroup (126 x 128 doubles); a wave holds two rows in registers, two columns per
+// lane, and applies a reflector with one 16-byte LDS read, four FMAs and two wave sums.
+constexpr int Q_TAIL_ROWS = 16;                           // rows per workgroup (8 waves x 2)
+constexpr int Q_TAIL_NT = 512;
+__global__ __launch_bounds__(Q_TAIL_NT) void k_q_tail_reflect(double *__restrict__ Q, int ldq, int nrows, int k0, int T, const double *__restrict__ A,
+                                                        int lda, const double *__restrict__ TAU, int q_is_unit)
+{
+    constexpr int TM = SYTD2_TAIL_T;
+    extern __shared__ __attribute__((aligned(16))) double vall[];          // reflector j at vall + j * TM (v[i] for block row i), then tau[TM]
+    double *taus = vall + (size_t)(TM - 2) * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nref = T - 2;
+#pragma unroll 8
+    for (int e = tid; e < nref * (TM / 2); e += Q_TAIL_NT) {
+        const int j = e / (TM / 2), i = (e % (TM / 2)) * 2;
+        double2_t v = {0.0, 0.0};
+        if (i + 1 < T) {                                                   // (k0 + i even offsets: lda and k0 are not known to be, so two loads)
+            const double *col = A + (size_t)(k0 + j) * lda + k0;
+            v.x = (i <= j) ? 0.0 : ((i == j + 1) ? 1.0 : col[i]);
+            v.y = (i + 1 <= j) ? 0.0 : ((i + 1 == j + 1) ? 1.0 : col[i + 1]);
+        } else if (i < T) {
+            v.x = (i <= j) ? 0.0 : ((i == j + 1) ? 1.0 : A[(size_t)(k0 + j) * lda + k0 + i]);
+        }
+        *reinterpret_cast<double2_t *>(vall + (size_t)j * TM + i) = v;
+    }
+    if (tid < TM) taus[tid] = (tid < nref) ? TAU[k0 + tid] : 0.0;
+    __syncthreads();
+    const int r0 = blockIdx.x * Q_TAIL_ROWS + wave * 2, r1 = r0 + 1, cc = 2 * lane;
+    // (q_is_unit: nothing has written Q yet — the block is the whole matrix — and it starts as the unit matrix)
+    auto ld = [&](int r, int col) { return (r < nrows && col < T) ? (q_is_unit ? (r == k0 + col ? 1.0 : 0.0) : Q[(size_t)r * ldq + k0 + col]) : 0.0; };
+    double q00 = ld(r0, cc), q01 = ld(r0, cc + 1), q10 = ld(r1, cc), q11 = ld(r1, cc + 1);
+    for (int j = 0; j < nref; ++j) {
+        const double2_t v = *reinterpret_cast<const double2_t *>(vall + (size_t)j * TM + cc);
+        const double tj = taus[j];
+        const double s0 = tj * wave_sum(q00 * v.x + q01 * v.y), s1 = tj * wave_sum(q10 * v.x + q11 * v.y);
+        q00 -= s0 * v.x;
+        q01 -= s0 * v.y;
+        q10 -= s1 * v.x;
+        q11 -= s1 * v.y;
+    }
+    if (r0 < nrows) {
+        if (cc < T) Q[(size_t)r0 * ldq + k0 + cc] = q00;
+        if (cc + 1 < T) Q[(size_t)r0 * ldq + k0 + cc + 1] = q01;
+    }
+    if (r1 < nrows) {
+        if (cc < T) Q[(size_t)r1 * ldq + k0 + cc] = q10;
+        if (cc + 1 < T) Q[(size_t)r1 * ldq + k0 + cc + 1] = q11;
     }
 }
 

@@ -28,4 +28,7 @@ for n in [int(a) for a in sys.argv[1:]] or [257, 510, 590]:
         torch.cuda.synchronize()
         ok = eg.check()
         res = float((dA @ U - U * w[None, :]).abs().max())
-        print("n=%4d two_stage=%s  %.3f ms per eigh  ok=%s residual %.1e" % (n, mode, e0.elapsed_time(e1) / 20, ok, res), flush=True)
+        orth = float((U.T @ U - torch.eye(n, device=dev, dtype=U.dtype)).abs().max())
+        werr = float((w - torch.linalg.eigvalsh(dA)).abs().max())
+        print("n=%4d two_stage=%s  %.3f ms per eigh  ok=%s residual %.1e orthogonality %.1e eigenvalues %.1e"
+              % (n, mode, e0.elapsed_time(e1) / 20, ok, res, orth, werr), flush=True)
