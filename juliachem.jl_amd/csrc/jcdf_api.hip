@@ -657,7 +657,7 @@ const DcPlan *dc_plan(int64_t n)
     DcPlan plan;
     std::vector<DcMerge> all;
     std::vector<std::pair<int, int>> blocks;                // (start, size)
-    for (int i = 0; i < (int)n; ++i) blocks.push_back({i, 1});
+    for (int i = 0; i < (int)n; i += DC_LEAF) blocks.push_back({i, std::min<int>(DC_LEAF, (int)n - i)});   // leaves: k_dc_leaf
     while (blocks.size() > 1) {
         DcLevel lv;
         lv.merge_off = all.size();
@@ -1917,11 +1917,14 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
     double *Za = (L % 2 == 0) ? d_Z : wk.Zb, *Zn = (L % 2 == 0) ? wk.Zb : d_Z;
     int64_t lda = (L % 2 == 0) ? ldz : wk.ldzb, ldn = (L % 2 == 0) ? wk.ldzb : ldz;
     double *wa = (L % 2 == 0) ? d_D : wk.w2, *wn = (L % 2 == 0) ? wk.w2 : d_D;
-    // (wa may be d_D itself: k_dc_init reads and writes only its own diagonal element per thread)
+    // (wa may be d_D itself: a leaf reads its own diagonal elements, and E, before it writes its eigenvalues over them)
     hipLaunchKernelGGL(k_dc_norm, dim3(1), dim3(256), 0, st, d_D, d_E, (int)n, wk.sc);
-    hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_D, d_E, (int)n, wa, Za, lda, Zn, ldn,
-                       wk.sc);
-    if (L == 0) hipLaunchKernelGGL(k_dc_unscale1, dim3(1), dim3(1), 0, st, wa, wk.sc);
+    hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, (int)n, Za, lda, Zn, ldn);
+    {
+        const int64_t leaves = (n + DC_LEAF - 1) / DC_LEAF;
+        hipLaunchKernelGGL(k_dc_leaf, dim3((unsigned)leaves), dim3(64), 0, st, (const double *)d_D,
+                           (const double *)d_E, (int)n, wa, Za, lda, (const double *)wk.sc, L == 0 ? 1 : 0);
+    }
     for (int l = 0; l < L; ++l) {
         const DcLevel &lv = plan->levels[l];
         const DcMerge *mg = plan->d_merges + lv.merge_off;

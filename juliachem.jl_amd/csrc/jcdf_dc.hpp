@@ -61,26 +61,132 @@ __global__ __launch_bounds__(256) void k_dc_norm(const double *__restrict__ d, c
     }
 }
 
-// ---- level 0: tear the matrix into 1 x 1 leaves -------------------------------------------------------
-// w[i] = d[i] - |e[i-1]| - |e[i]|  (every off-diagonal is a tear), Z = I; the second (ping-pong) buffer
-// is zeroed: every level writes only the diagonal blocks of its merges and the next level relies on the
-// blocks between two children being zero.
-__global__ void k_dc_init(const double *__restrict__ d, const double *__restrict__ e, int n, double *__restrict__ w,
-                          double *__restrict__ Z, int64_t ldz, double *__restrict__ Z2, int64_t ldz2,
-                          const double *__restrict__ sc)
+// ---- level 0: tear the matrix into leaves of DC_LEAF rows and solve them directly ---------------------------------
+// Both eigenvector buffers are zeroed: every level writes only the diagonal blocks of its merges and the next level
+// relies on the blocks between two children being zero.
+__global__ void k_dc_init(int n, double *__restrict__ Z, int64_t ldz, double *__restrict__ Z2, int64_t ldz2)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) {
-        const int i = (int)idx;
-        w[i] = (d[i] - (i > 0 ? fabs(e[i - 1]) : 0.0) - (i < n - 1 ? fabs(e[i]) : 0.0)) * sc[1];
-    }
     if (idx < (int64_t)n * n) {
-        Z[(idx / n) * ldz + idx % n] = (idx / n == idx % n) ? 1.0 : 0.0;
+        Z[(idx / n) * ldz + idx % n] = 0.0;
         Z2[(idx / n) * ldz2 + idx % n] = 0.0;
     }
 }
 
-__global__ void k_dc_unscale1(double *__restrict__ w, const double *__restrict__ sc) { w[0] *= sc[0]; }   // n == 1
+// Leaf s .. s + m - 1 (m <= DC_LEAF) of the torn matrix: diagonal d - |e| at a torn end (every block boundary is a tear,
+// rho = 2 |e| in the merge that mends it), off-diagonals as they are, all scaled by sc[1].  Implicit QL with Wilkinson
+// shifts (EISPACK tql2 / LAPACK dsteqr's algorithm) — three levels of 2-, 4- and 8-row merges were three launches of
+// ~25 us of pure latency; this one takes 31 us at n = 510 (64 leaves).  One leaf per workgroup of eight lanes (leaves sharing a wave would wait for each other's
+// data-dependent loops): every lane runs the same scalar recurrence on its own copy of d and e (LDS used as indexable
+// private memory, element-major so that the lanes sit on different banks) and lane r rotates row r of the eigenvector
+// matrix, so nothing is exchanged between lanes and no barrier is needed.  The rotations take 1 / sqrt(f^2 + g^2) from the
+// hardware estimate + two Newton steps (full precision) instead of a square root and two divisions: the recurrence is one
+// dependent chain, and the IEEE expansions and the LDS round trips inside it were most of its time.
+// Out: w[s + k] ascending, row s + k of Z = eigenvector k (components in columns s ..).
+constexpr int DC_LEAF = 8;
+__global__ __launch_bounds__(64) void k_dc_leaf(const double *__restrict__ d, const double *__restrict__ e, int n, double *__restrict__ w,
+                                                double *__restrict__ Z, int64_t ldz, const double *__restrict__ sc, int last)
+{
+    __shared__ double sd[DC_LEAF][DC_LEAF], se[DC_LEAF][DC_LEAF], sz[DC_LEAF][DC_LEAF];
+    const int lane = threadIdx.x, r = lane;
+    const int s = blockIdx.x * DC_LEAF;
+    const int m = n - s < DC_LEAF ? n - s : DC_LEAF;
+    if (m <= 0 || lane >= DC_LEAF) return;
+    const double scale = sc[1];
+    for (int i = 0; i < DC_LEAF; ++i) {
+        double di = 0.0, ei = 0.0;
+        if (i < m) {
+            di = d[s + i];
+            if (i == 0 && s > 0) di -= fabs(e[s - 1]);
+            if (i == m - 1 && s + m < n) di -= fabs(e[s + m - 1]);
+            di *= scale;
+            if (i < m - 1) ei = e[s + i] * scale;
+        }
+        sd[i][lane] = di;
+        se[i][lane] = ei;
+        sz[i][lane] = (i == r) ? 1.0 : 0.0;               // row r of the unit matrix
+    }
+    const double eps = 2.0 * DC_EPS;
+    for (int l = 0; l < m; ++l) {
+        int iter = 0, mm;
+        do {
+            // first negligible off-diagonal at or after l: lane j tests position j of its own (identical) copy, one ballot
+            {
+                const bool small = lane >= l && lane < m - 1 &&
+                                   fabs(se[lane][lane]) <= eps * (fabs(sd[lane][lane]) + fabs(sd[lane < DC_LEAF - 1 ? lane + 1 : lane][lane]));
+                const unsigned long long hit = __ballot(small);
+                mm = hit ? (int)__builtin_ctzll(hit) : m - 1;
+            }
+            if (mm != l) {
+                if (iter++ == 60) break;                  // (never seen; the merges above would then deflate garbage, so stop here)
+                const double el = se[l][lane], dl = sd[l][lane];
+                // Wilkinson shift (reciprocals and the root by estimate + two Newton steps, as in the rotations below)
+                auto recip = [](double x) { double y = __builtin_amdgcn_rcp(x); y = y * (2.0 - x * y); return y * (2.0 - x * y); };
+                double g = (sd[l + 1][lane] - dl) * recip(2.0 * el);
+                const double g21 = g * g + 1.0;
+                double rq = __builtin_amdgcn_rsq(g21);
+                rq = rq * (1.5 - 0.5 * g21 * rq * rq);
+                rq = rq * (1.5 - 0.5 * g21 * rq * rq);
+                double rr = g21 * rq;
+                g = sd[mm][lane] - dl + el * recip(g + copysign(rr, g));
+                double sn = 1.0, cs = 1.0, p = 0.0;
+                // the chase, i = mm-1 .. l.  What a rotation reads was either produced by the one before it (carried in
+                // registers: d_c = d[i+1], z_c = z[i+1]) or is untouched so far and fetched one rotation ahead
+                // (e_i, d_i, z_i): the dependent chain is arithmetic only.
+                double e_i = se[mm - 1][lane], d_i = sd[mm - 1][lane], z_i = sz[mm - 1][lane];
+                double d_c = sd[mm][lane], z_c = sz[mm][lane];
+                int i;
+                for (i = mm - 1; i >= l; --i) {
+                    const int ip = i > 0 ? i - 1 : 0;
+                    const double e_n = se[ip][lane], d_n = sd[ip][lane], z_n = sz[ip][lane];
+                    const double f = sn * e_i, b = cs * e_i;
+                    const double h2 = f * f + g * g;
+                    double ri = __builtin_amdgcn_rsq(h2);                     // (h2 == 0: inf, not used)
+                    ri = ri * (1.5 - 0.5 * h2 * ri * ri);
+                    ri = ri * (1.5 - 0.5 * h2 * ri * ri);
+                    rr = (h2 == 0.0) ? 0.0 : h2 * ri;
+                    se[i + 1][lane] = rr;
+                    if (rr == 0.0) {
+                        sd[i + 1][lane] = d_c - p;
+                        se[mm][lane] = 0.0;
+                        break;
+                    }
+                    sn = f * ri;
+                    cs = g * ri;
+                    g = d_c - p;
+                    rr = (d_i - g) * sn + 2.0 * cs * b;
+                    p = sn * rr;
+                    sd[i + 1][lane] = g + p;
+                    g = cs * rr - b;
+                    sz[i + 1][lane] = sn * z_i + cs * z_c;
+                    z_c = cs * z_i - sn * z_c;
+                    sz[i][lane] = z_c;
+                    d_c = d_i;
+                    e_i = e_n;
+                    d_i = d_n;
+                    z_i = z_n;
+                }
+                if (rr == 0.0 && i >= l) continue;
+                sd[l][lane] = d_c - p;
+                se[l][lane] = g;
+                se[mm][lane] = 0.0;
+            }
+        } while (mm != l);
+    }
+    // ascending order (ties: lower index first), eigenvector k = column k of the rotated unit matrix: lane r holds its component r
+    const double unscale = last ? sc[0] : 1.0;
+    for (int k = 0; k < m; ++k) {
+        const double dk = sd[k][lane];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const double dj = sd[j][lane];
+            rank += (dj < dk || (dj == dk && j < k)) ? 1 : 0;
+        }
+        if (r == 0) w[s + rank] = dk * unscale;
+        if (r < m) Z[(int64_t)(s + rank) * ldz + s + r] = sz[k][lane];
+    }
+}
+
 
 // ---- prepare: one workgroup per merge ---------------------------------------------------------------------
 // In : w (eigenvalues of the two children, each ascending), Z (their eigenvectors, block diagonal), e.

@@ -1,5 +1,5 @@
-// jcdf_eig.hpp — k_sytrd_lower / k_sytrd_onehop: Householder tridiagonalisation of a symmetric fp64
-// matrix in ONE persistent kernel launch (caller side of the hot path, SURVEY 8 row f1: the
+// jcdf_eig.hpp — k_sytrd_lower / k_sytrd_onehop (+ k_sytd2_tail): Householder tridiagonalisation of a symmetric
+// fp64 matrix in ONE persistent kernel launch and a one-workgroup finish (caller side of the hot path, SURVEY 8 row f1: the
 // replicated eigensolve of `iteration`, /root/reference/src/rhf/energy/SCF.jl:1080-1083).
 //
 // Why: rocSOLVER's syevd spends ~9 of its 12 ms (N = 510) in ~4000 tiny latrd/symv/syr2
@@ -14,7 +14,9 @@
 // rounds per column: k_sytrd_lower has two (reflector v + tau, then y = tau A v), k_sytrd_onehop one
 // (every workgroup forms the reflector itself from a column that was broadcast a step ahead).
 // History at N = 510, us per column: 7.5 (two counter grid barriers) -> 7.0 (granules) -> 5.9 (reductions
-// by DPP instead of ds_bpermute, Q accumulated in the kernel) -> 5.0 (tau travels with v) -> 4.6 (one hop).
+// by DPP instead of ds_bpermute, Q accumulated in the kernel) -> 5.0 (tau travels with v) -> 4.6 (one hop)
+// -> 4.1 over the whole matrix once the LAST 128 columns are reduced by one workgroup from its register file
+// (k_sytd2_tail below: 1.7 us per column, no hand-off; k_q_tail_reflect applies its reflectors to Q).
 //
 // Output is LAPACK-compatible (dsytrd 'L'): D, E, TAU and the Householder vectors below the
 // sub-diagonal of A (handed-off values rounded to 50 mantissa bits, see below), plus optionally the

@@ -1,5 +1,7 @@
 // Phase timeline of k_sytrd_lower (workgroup 1): hipcc --offload-arch=gfx950 -O3 -DJCDF_SYTRD_PROFILE -o sytrd_prof sytrd_prof.hip
+#include "../juliachem.jl_amd/csrc/jcdf_gemm.hpp"
 #include "../juliachem.jl_amd/csrc/jcdf_eig.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -26,12 +28,11 @@ int main(int argc, char **argv)
     const int nthr = argc > 5 ? atoi(argv[5]) : 256;
     const int onehop = argc > 6 ? atoi(argv[6]) : 0;             // 1: k_sytrd_onehop
     const size_t lds = onehop ? ((size_t)ncol * n + 5 * n + 32) * 8 : ((size_t)(withq ? 2 : 1) * ncol * n + 2 * n + 32) * 8;
-    if (onehop && (ncol > 8 || n > 1280)) { printf("onehop needs <= 8 columns per workgroup and n <= 1280\n"); return 1; }
+    if (onehop && (ncol > 8 || n > 1000)) { printf("onehop needs <= 8 columns per workgroup and n <= 1000\n"); return 1; }
     double *dQ; hipMalloc(&dQ, A.size() * 8);
-    hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void *)k_sytrd_onehop<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void *)k_sytrd_onehop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void *)k_sytrd_onehop<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // columns 0 .. kstop-1 in the chip-wide kernel (the library stops 128 columns early and hands the rest to k_sytd2_tail)
+    const int kstop = argc > 7 ? atoi(argv[7]) : (n > 128 ? n - 128 : n);
+    u64 *vg = (u64 *)(w + 64), *yg = vg + 2 * (n + 2), *hg = yg + 2 * ((n + 1) & ~1);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
         hipMemset(w, 0, wb);
@@ -39,18 +40,23 @@ int main(int argc, char **argv)
         hipMemcpyToSymbol(HIP_SYMBOL(g_sytrd_prof), zero, sizeof(zero));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        if (onehop && n > 1024)
-            hipLaunchKernelGGL(k_sytrd_onehop<40>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                               (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
-        else if (onehop && n > 640)
-            hipLaunchKernelGGL(k_sytrd_onehop<32>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                               (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
-        else if (onehop)
-            hipLaunchKernelGGL(k_sytrd_onehop<20>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                               (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
-        else
-        hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, (u64 *)(w + 64),
-                           (u64 *)(w + 64) + 2 * (n + 2), (u64 *)(w + 64) + 2 * (n + 2) + 2 * ((n + 1) & ~1), (int *)(w + 8), withq ? dQ : nullptr);
+#define ONEHOP(NR)                                                                                                                   \
+    do {                                                                                                                             \
+        hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+        hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, vg, yg, hg, (int *)(w + 8),         \
+                           withq ? dQ : nullptr, n, kstop);                                                                          \
+    } while (0)
+        if (onehop) {                                        // the library's choice of the rows-per-lane template (jcdf_sytrd_q_device)
+            if (n <= 64) ONEHOP(2);
+            else if (n <= 256) ONEHOP(8);
+            else if (n <= 512) ONEHOP(16);
+            else if (n <= 640) ONEHOP(20);
+            else ONEHOP(32);
+        } else {
+            hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_sytrd_lower, dim3(G), dim3(nthr), lds, 0, dA, n, n, dD, dE, dT, vg, yg, hg, (int *)(w + 8),
+                               withq ? dQ : nullptr, n, kstop);
+        }
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         u64 p[8]; hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sytrd_prof), sizeof(p));
@@ -60,11 +66,12 @@ int main(int argc, char **argv)
         double tr = 0, trT = 0, fr = 0, frT = 0;
         for (int i = 0; i < n; ++i) { tr += A[(size_t)i * n + i]; trT += d[i]; frT += d[i] * d[i] + (i < n - 1 ? 2 * e[i] * e[i] : 0); }
         for (size_t i = 0; i < A.size(); ++i) fr += A[i] * A[i];
-        printf("   invariants: trace %.3e  frob^2 rel %.3e\n", tr - trT, (fr - frT) / fr);
+        if (kstop >= n) printf("   invariants: trace %.3e  frob^2 rel %.3e\n", tr - trT, (fr - frT) / fr);
         printf("n=%d G=%d T=%d lds=%zu: %.3f ms (%.2f us/col) err=%d | per column us: wait_v %.2f  y %.2f  Q %.2f  wait_y %.2f  update %.2f\n", n, G, nthr, lds, ms,
-               1e3 * ms / n, err, p[0] / 100.0 / n, p[1] / 100.0 / n, p[4] / 100.0 / n, p[2] / 100.0 / n, p[3] / 100.0 / n);
+               1e3 * ms / std::min(n, kstop), err, p[0] / 100.0 / std::min(n, kstop), p[1] / 100.0 / std::min(n, kstop), p[4] / 100.0 / std::min(n, kstop),
+               p[2] / 100.0 / std::min(n, kstop), p[3] / 100.0 / std::min(n, kstop));
     }
-    if (withq) {          // Q^T A Q == T and Q^T Q == I
+    if (withq && kstop >= n) {          // Q^T A Q == T and Q^T Q == I (complete reductions only)
         std::vector<double> Q(A.size()), d(n), e(n), AQ(A.size());
         hipMemcpy(Q.data(), dQ, A.size() * 8, hipMemcpyDeviceToHost);
         hipMemcpy(d.data(), dD, n * 8, hipMemcpyDeviceToHost); hipMemcpy(e.data(), dE, n * 8, hipMemcpyDeviceToHost);
