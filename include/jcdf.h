@@ -213,7 +213,9 @@ int32_t jcdf_device_potrf_trtri(int32_t device_id, double *A, int64_t n);
 /* Caller-side helper for the replicated eigensolve of the SCF iteration (reference: host
  * LAPACK eigen!(Hermitian(.)) at src/rhf/energy/SCF.jl:1083): Householder tridiagonalisation
  * (LAPACK dsytrd 'L' semantics: D, E, TAU and reflectors below the sub-diagonal of A, column-
- * major) of the symmetric n x n device matrix d_A in ONE persistent kernel on `stream`.
+ * major) of the symmetric n x n device matrix d_A on `stream`: ONE persistent chip-wide kernel for
+ * the columns 0 .. n-129 and a one-workgroup kernel for the last 128 (a matrix of 32 .. 128 rows goes
+ * to the latter whole).  The upper triangle of d_A is scratch.
  * d_work: jcdf_sytrd_workspace_bytes(n) bytes of device memory; its int at byte offset 8 is
  * non-zero afterwards if the in-kernel grid barrier timed out (result invalid).  n <~ 2200. */
 int64_t jcdf_sytrd_workspace_bytes(int64_t n);
@@ -221,9 +223,9 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
                           double *d_TAU, void *d_work, int64_t work_bytes);
 /* Same, and additionally d_Q (n x n, row-major == the transpose in column-major) receives the
  * orthogonal matrix Q = H_0 H_1 ... of A = Q T Q^T (row stride ldq >= n, so that it can be written straight into a zero
- * padded GEMM operand), accumulated inside the same kernel while the
- * reflectors travel between workgroups, so the eigenvectors of A are ONE GEMM Q*Z away (instead of
- * LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
+ * padded GEMM operand), accumulated inside the chip-wide kernel while the
+ * reflectors travel between workgroups (the last 128 reflectors by one row-parallel launch), so the
+ * eigenvectors of A are ONE GEMM Q*Z away (instead of LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
  * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above). */
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes);
