@@ -124,3 +124,31 @@ def test_engine_matches_oracle_on_a_water_dimer():
     T_all = eng.calculate_three_center_integrals(range(0, int(pos[6])), None).reshape(-1, N, N, order="F")
     assert np.abs(T_all[:, ~mask]).max() < 1e-5                        # what is screened is below sigma: |(P|pq)| <= sqrt((P|P)(pq|pq))
     eng.close()
+
+
+@pytest.mark.parametrize("nc", [1, 2])
+def test_engine_matches_oracle_on_alkanes_with_carbon_tables(nc):
+    """Carbon and hydrogen in 6-31G(2df,p) / cc-pVTZ-JKFIT (the tables of the reference's benzene-methane log: sp shells, two d
+    and one f shell on C, auxiliary functions up to g on C and f on H): methane and ethane against the oracle's independent
+    numpy code — the element and the basis pair of the S22 complexes and of bench.py's real molecule (the water cases above
+    hold no carbon)."""
+    from oracle import integrals as gi
+    from juliachem_jl_amd.synthetic import n_alkane
+    d = json.load(open(os.path.join(GOLDEN, "s22_10_benzene_methane_631g2dfp_jkfit.json")))
+    atoms = n_alkane(nc)
+    eng = HostIntegralEngine(atoms, d["basis"], d["aux_basis"], d["charges"])
+    prim = gi.build_shells(atoms, d["basis"]); aux = gi.build_shells(atoms, d["aux_basis"])
+    Z = [d["charges"][a["symbol"]] for a in atoms]; R = np.array([a["center"] for a in atoms])
+    assert eng.prim.shell_nbas == [s.nbas for s in prim] and eng.aux.shell_nbas == [s.nbas for s in aux]
+    S, T, V = eng.one_electron()
+    So, To, Vo = gi.one_electron(prim, Z, R)
+    assert np.abs(S - So).max() < 1e-13 and np.abs(T - To).max() < 1e-11 and np.abs(V - Vo).max() < 1e-10
+    assert abs(eng.nuclear_repulsion() - gi.nuclear_repulsion(Z, R)) < 1e-11
+    J = eng.calculate_two_center_intgrals()
+    Jo = gi.two_center(aux)
+    assert np.abs(J - np.tril(Jo)).max() < 1e-12 * np.abs(Jo).max()
+    N, Q = eng.prim.nbf, eng.aux.nbf
+    T3 = eng.calculate_three_center_integrals(range(Q), None)
+    ref = gi.three_center(aux, prim)
+    assert np.abs(T3 - ref.reshape(Q, N * N, order="F")).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    eng.close()
