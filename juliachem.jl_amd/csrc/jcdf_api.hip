@@ -1521,10 +1521,11 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     // N = 240: 0.93 vs 1.08 ms, 510: 2.43 vs 2.59, 700: 3.93 vs 3.99, 1000: 6.90 vs 6.50 (tools/sytrd_prof.hip)
     static const int onehop_env = diag_env("JCDF_SYTRD_ONEHOP") ? atoi(diag_env("JCDF_SYTRD_ONEHOP")) : -1;
     // (with every poll of a thread in flight at once, sub_two_n, the one-exchange kernel also wins at n = 700: 3.86 vs 3.98 ms and
-    //  956: 5.86 vs 6.11 ms; at n = 1250 the two-exchange kernel with 512 threads stays ahead: 8.70 vs 8.89 ms)
-    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1000;
+    //  956: 5.86 vs 6.11 ms; with 512 threads — one WAVE per column in the fused pass and per row of Q — it wins wherever its
+    //  slabs fit the LDS: whole eigensolve n = 1000 6.53 -> 5.26 ms, n = 1250 9.01 (two exchanges) -> 7.66, n = 1500 13.3)
+    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1536;
     if (kstop == 0) return finish();                                     // the whole matrix is the tail (Q starts as the unit matrix there)
-    if (onehop && n <= 1000) {
+    if (onehop && n <= 1536) {
         int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
         if (const char *e = diag_env("JCDF_SYTRD_G1")) G1 = std::max(G1, std::min(256, atoi(e)));                 // diagnostic builds: more workgroups
         const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
@@ -1532,14 +1533,16 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     do {                                                                                                                    \
         if (hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) \
             return JCDF_ERR_HIP;                                                                                            \
-        hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(256), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
+        hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(512), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
                            d_TAU, vg, yg, hg, err, d_Q, (int)ldq, kstop);                                                   \
     } while (0)
         if (n <= 64) JCDF_ONEHOP(2);
         else if (n <= 256) JCDF_ONEHOP(8);
         else if (n <= 512) JCDF_ONEHOP(16);
         else if (n <= 640) JCDF_ONEHOP(20);
-        else JCDF_ONEHOP(32);
+        else if (n <= 1024) JCDF_ONEHOP(32);
+        else if (n <= 1280) JCDF_ONEHOP(40);
+        else JCDF_ONEHOP(48);
 #undef JCDF_ONEHOP
         return finish();
     }

@@ -16,7 +16,10 @@
 // History at N = 510, us per column: 7.5 (two counter grid barriers) -> 7.0 (granules) -> 5.9 (reductions
 // by DPP instead of ds_bpermute, Q accumulated in the kernel) -> 5.0 (tau travels with v) -> 4.6 (one hop)
 // -> 4.1 over the whole matrix once the LAST 128 columns are reduced by one workgroup from its register file
-// (k_sytd2_tail below: 1.7 us per column, no hand-off; k_q_tail_reflect applies its reflectors to Q).
+// (k_sytd2_tail below: 1.7 us per column, no hand-off; k_q_tail_reflect applies its reflectors to Q)
+// -> 3.5 with 512 threads in the one-hop kernel: one 64-lane wave per column in the fused pass and per row of Q — what
+// a step waits for is its dependent chain, and the per-lane length of these two loops was a third of it (the polled volume
+// and the sharing of its cache lines are not: profiles/r03_sytd2_tail.txt).
 //
 // Output is LAPACK-compatible (dsytrd 'L'): D, E, TAU and the Householder vectors below the
 // sub-diagonal of A (handed-off values rounded to 50 mantissa bits, see below), plus optionally the
@@ -540,9 +543,10 @@ __device__ __forceinline__ bool sub_two(const u64 *g1, unsigned tag1, double *ds
 //      published at once; the owner of column k+2 broadcasts that column (now in the state step k+1 needs).
 // Buffers (parity of the item index), tags and the heartbeat rule as in k_sytrd_lower; here the heartbeat (k) is
 // fresh: a workgroup with no column > k publishes it where the others publish y_k.
-// LDS: (ncol_max * n + 5 n + 32) doubles; requires n <= 32 NR and at most 8 columns per workgroup.
+// LDS: (ncol_max * n + 5 n + 32) doubles; requires n <= 32 NR and at most 8 columns per workgroup; 512 threads (8 waves:
+// wave w takes my column c0 + w in the fused pass e. and holds my w-th row of Q).
 template <int NR>
-__global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
+__global__ __launch_bounds__(512) void k_sytrd_onehop(double *__restrict__ A, int lda, int n, double *__restrict__ D,
                                                       double *__restrict__ E, double *__restrict__ TAU,
                                                       u64 *cg, u64 *yg, u64 *hg, int *err, double *__restrict__ Qout, int ldq, int kstop)
 {
@@ -564,12 +568,14 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
     unsigned rs = 0;
     const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;
     const int ne = (n + 1) & ~1, nv = n + 2;              // buffer strides (even)
-    // my rows of Q live in REGISTERS: 32-lane group `ce` holds row g + ce*G (nc <= 8 = groups per workgroup, n <= 32 NR),
-    // lane `seg` its elements seg, seg+32, ... — the Q update then only reads v from LDS
-    const bool haveq = Qout && ce < nc;
-    double qreg[NR];
+    // my rows of Q live in REGISTERS: wave `wq` holds row g + wq*G (nc <= 8 = waves per workgroup, n <= 32 NR), lane `lq` its
+    // elements lq, lq+64, ... — the Q update then only reads v from LDS
+    constexpr int NRW = (NR + 1) / 2;
+    const int wq = tid >> 6, lq = tid & 63;
+    const bool haveq = Qout && wq < nc;
+    double qreg[NRW];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) qreg[r] = (haveq && seg + 32 * r == g + ce * G) ? 1.0 : 0.0;
+    for (int r = 0; r < NRW; ++r) qreg[r] = (haveq && lq + 64 * r == g + wq * G) ? 1.0 : 0.0;
     for (int c = 0; c < nc; ++c)
         for (int i = tid; i < n; i += nthr) slab[(size_t)c * n + i] = A[(size_t)(g + c * G) * lda + i];
     for (int i = tid; i < n; i += nthr) vs[i] = ws[i] = 0.0;                // "update -1" is empty
@@ -585,22 +591,16 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
         const int r0 = k + 1, m = n - r0;                 // rows r0 .. n-1, relative index i <-> row r0 + i
         // ---- a. while y_k travels: Q <- Q H_k on my row of Q (registers; v_k from LDS, index = column - r0)
         if (Qout && k >= 0) {
-            double vr[NR], sq = 0.0;
+            double vr[NRW], sq = 0.0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int c = seg + 32 * r;
-                vr[r] = (32 * r + 31 >= r0 && c >= r0 && c < n) ? vs[c - r0] : 0.0;
+            for (int r = 0; r < NRW; ++r) {
+                const int c = lq + 64 * r;
+                vr[r] = (64 * r + 63 >= r0 && c >= r0 && c < n) ? vs[c - r0] : 0.0;
                 sq += qreg[r] * vr[r];
             }
-            const double h = half_sums(sq);
-            const long long hb_ = __double_as_longlong(h);
-            const int lo31 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 31);
-            const int lo63 = __builtin_amdgcn_readlane((int)(hb_ & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb_ >> 32), 63);
-            const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
-                                          : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
-            const double sc = tau * tot;
+            const double sc = tau * wave_sum(sq);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) qreg[r] -= sc * vr[r];
+            for (int r = 0; r < NRW; ++r) qreg[r] -= sc * vr[r];
         }
         SYTRD_TICK(4);                                    // Q accumulation
         // ---- b + c. column r0 and y_k (+ heartbeat of the workgroups without a column > k), ONE round of polls
@@ -677,26 +677,16 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
             u64 *ynb = yg + (size_t)((k + 1) & 1) * ne;
             u64 *cnb = cg + (size_t)((r0 + 1) & 1) * nv;
             const unsigned ytag = step_tag(k + 1), ctag = step_tag(r0 + 1);
-            for (int cbase = c0; cbase < nc; cbase += cpp) {
-                const bool have = cbase + ce < nc;
-                const int j = g + (have ? cbase + ce : c0) * G;
-                double *col = slab + (size_t)(have ? cbase + ce : c0) * n + r0;
+            // one WAVE per column (512 threads: eight columns at once), 64 rows per pass, the column's y by one wave sum
+            const int wv = tid >> 6, ln = tid & 63, nwv = nthr >> 6;
+            for (int cbase = c0; cbase < nc; cbase += nwv) {
+                const bool have = cbase + wv < nc;
+                const int j = g + (have ? cbase + wv : c0) * G;
+                double *col = slab + (size_t)(have ? cbase + wv : c0) * n + r0;
                 const double wj = ws[j - r0], vj = vs[j - r0];
                 const bool send = have && j == r0 + 1;
-                double s0 = 0.0, s1 = 0.0;
-                int i = seg;
-                for (; i + 32 < m; i += 64) {
-                    const double x0 = col[i] - (vs[i] * wj + ws[i] * vj);
-                    const double x1 = col[i + 32] - (vs[i + 32] * wj + ws[i + 32] * vj);
-                    if (have) { col[i] = x0; col[i + 32] = x1; }
-                    if (i >= 1) s0 += x0 * (i == 1 ? 1.0 : cs[i] * scale);
-                    s1 += x1 * cs[i + 32] * scale;                            // i + 32 >= 2 always
-                    if (send) {
-                        if (i >= 1) pub(cnb, i - 1, x0, ctag);
-                        pub(cnb, i + 31, x1, ctag);
-                    }
-                }
-                if (i < m) {
+                double s0 = 0.0;
+                for (int i = ln; i < m; i += 64) {
                     const double x0 = col[i] - (vs[i] * wj + ws[i] * vj);
                     if (have) col[i] = x0;
                     if (i >= 1) {
@@ -704,8 +694,8 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
                         if (send) pub(cnb, i - 1, x0, ctag);
                     }
                 }
-                const double sy = half_sums(s0 + s1);
-                if (seg == 31 && have) pub(ynb, j - (r0 + 1), tau_next * sy, ytag);
+                const double sy = wave_sum(s0);
+                if (ln == 0 && have) pub(ynb, j - (r0 + 1), tau_next * sy, ytag);
             }
             if (tid == 0 && lastcol <= k + 1) pub(hg + (size_t)((k + 1) & 1) * G, g, 0.0, ytag);     // heartbeat (k+1)
         }
@@ -721,8 +711,8 @@ __global__ __launch_bounds__(256) void k_sytrd_onehop(double *__restrict__ A, in
         for (int i = tid; i < n; i += nthr) A[(size_t)(g + c * G) * lda + i] = slab[(size_t)c * n + i];
     if (haveq) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (seg + 32 * r < n) Qout[(size_t)(g + ce * G) * ldq + seg + 32 * r] = qreg[r];
+        for (int r = 0; r < NRW; ++r)
+            if (lq + 64 * r < n) Qout[(size_t)(g + wq * G) * ldq + lq + 64 * r] = qreg[r];
     }
 }
 
