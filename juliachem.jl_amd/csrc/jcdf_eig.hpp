@@ -686,12 +686,30 @@ __global__ __launch_bounds__(512) void k_sytrd_onehop(double *__restrict__ A, in
                 const double wj = ws[j - r0], vj = vs[j - r0];
                 const bool send = have && j == r0 + 1;
                 double s0 = 0.0;
-                for (int i = ln; i < m; i += 64) {
-                    const double x0 = col[i] - (vs[i] * wj + ws[i] * vj);
-                    if (have) col[i] = x0;
-                    if (i >= 1) {
-                        s0 += x0 * (i == 1 ? 1.0 : cs[i] * scale);
-                        if (send) pub(cnb, i - 1, x0, ctag);
+                // four passes' operands are fetched before the first result is stored: the compiler cannot move a load above the
+                // store of the pass before (all of it is one LDS array to it), and a lane's passes would run one LDS latency each
+                for (int i = ln; i < m; i += 256) {
+                    double cc[4], vv[4], wwv[4], zz[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ii = i + 64 * u;
+                        const bool in = ii < m;
+                        cc[u] = in ? col[ii] : 0.0;
+                        vv[u] = in ? vs[ii] : 0.0;
+                        wwv[u] = in ? ws[ii] : 0.0;
+                        zz[u] = in ? cs[ii] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ii = i + 64 * u;
+                        if (ii < m) {
+                            const double x0 = cc[u] - (vv[u] * wj + wwv[u] * vj);
+                            if (have) col[ii] = x0;
+                            if (ii >= 1) {
+                                s0 += x0 * (ii == 1 ? 1.0 : zz[u] * scale);
+                                if (send) pub(cnb, ii - 1, x0, ctag);
+                            }
+                        }
                     }
                 }
                 const double sy = wave_sum(s0);
