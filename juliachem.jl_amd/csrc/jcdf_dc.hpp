@@ -360,12 +360,31 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
 // ---- secular equation ------------------------------------------------------------------------------------
 // Root j of f(x) = 1 + rho sum_i z_i^2/(d_i - x) in (d_j, d_{j+1}) (last: (d_K, d_K + rho |z|^2]),
 // returned as (origin o, mu) with lambda = d_o + mu, o the nearer pole.  LANES lanes share the sums.
+// (on the VALU by DPP where the group is a quad, a row or the wave — jcdf_eig.hpp; a double __shfl_xor is two trips through
+//  the LDS crossbar, and an evaluation of the secular function makes 24 of them: with the division below, most of its time)
 template <int LANES>
 __device__ __forceinline__ double lanes_sum(double x)
 {
+    if constexpr (LANES == 64) return wave_sum(x);
+    else if constexpr (LANES == 16) return row16_sum(x);
+    else if constexpr (LANES == 4) {
+        x += dpp_f64<0xB1, 0xf>(x);      // quad_perm [1,0,3,2]
+        x += dpp_f64<0x4E, 0xf>(x);      // quad_perm [2,3,0,1]
+        return x;
+    } else {
 #pragma unroll
-    for (int off = LANES / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, LANES);
-    return x;
+        for (int off = LANES / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, LANES);
+        return x;
+    }
+}
+
+// 1 / x by the hardware estimate + two Newton steps (full double precision, not correctly rounded): the IEEE division is a
+// chain of ~25 dependent instructions, and the sums below are one division per pole
+__device__ __forceinline__ double dc_recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    return y * (2.0 - x * y);
 }
 
 template <int LANES>
@@ -377,7 +396,7 @@ __device__ void dc_secular_root(int j, int K, const double *__restrict__ d, cons
         double a = 0.0, da = 0.0, b = 0.0, db = 0.0;
         const double dorg = d[o];
         for (int i = lane; i < K; i += LANES) {
-            const double t = z[i] / ((d[i] - dorg) - mu);
+            const double t = z[i] * dc_recip((d[i] - dorg) - mu);
             const double zt = z[i] * t;
             if (i <= j) { a += zt; da += t * t; } else { b += zt; db += t * t; }
         }

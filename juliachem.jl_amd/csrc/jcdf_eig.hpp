@@ -1062,9 +1062,18 @@ __global__ __launch_bounds__(64) void k_diis_solve(double *__restrict__ Bmat, co
     const int tid = threadIdx.x;
     if (tid < nd) {
         double d = 0.0;
-        if (nparts > 0)
-            for (int k = 0; k < nparts; ++k) d += dots[tid * nparts + k];
-        else
+        if (nparts > 0) {
+            // (fixed order; eight loads in flight at a time instead of one after the other)
+            int k = 0;
+            for (; k + 8 <= nparts; k += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = dots[tid * nparts + k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d += t[u];
+            }
+            for (; k < nparts; ++k) d += dots[tid * nparts + k];
+        } else
             d = dots[tid];
         Bmat[(size_t)head * nd + tid] = d;
         Bmat[(size_t)tid * nd + head] = d;
@@ -1084,15 +1093,18 @@ __global__ __launch_bounds__(64) void k_diis_solve(double *__restrict__ Bmat, co
     __syncthreads();
     bool bad = false;
     for (int c = 0; c < m; ++c) {
-        if (tid == 0) {                                   // partial pivoting
-            int p = c;
-            double best = fabs(M[c][c]);
-            for (int r = c + 1; r < m; ++r)
-                if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
-            piv_row = (best > 0.0 && isfinite(best)) ? p : -1;
+        // partial pivoting, by the whole wave: lane r offers |M[r][c]|, the first lane holding the maximum is the pivot row
+        // (the row a serial search with a strict '>' finds)
+        int p;
+        {
+            const bool in = tid >= c && tid < m;
+            const double mine = in ? fabs(M[tid][c]) : -1.0;
+            double best = mine;                                                  // (fmax passes over a NaN: it fails the solve later)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off, 64));
+            const unsigned long long who = __ballot(in && mine == best && best > 0.0 && isfinite(best));
+            p = who ? (int)__builtin_ctzll(who) : -1;
         }
-        __syncthreads();
-        const int p = piv_row;
         if (p < 0) { bad = true; break; }
         if (p != c) {
             if (tid < m) { const double t = M[c][tid]; M[c][tid] = M[p][tid]; M[p][tid] = t; }
@@ -1107,14 +1119,16 @@ __global__ __launch_bounds__(64) void k_diis_solve(double *__restrict__ Bmat, co
         }
         __syncthreads();
     }
-    if (!bad && tid == 0) {                               // back substitution
+    if (!bad) {                                           // back substitution, column-oriented: every lane forms x_r, lane j < r updates rhs[j]
         for (int r = m - 1; r >= 0; --r) {
-            double x = rhs[r];
-            for (int j = r + 1; j < m; ++j) x -= M[r][j] * rhs[j];
-            rhs[r] = x / M[r][r];
-            if (!isfinite(rhs[r])) bad = true;
+            const double x = rhs[r] / M[r][r];
+            if (!isfinite(x)) bad = true;                 // (the same value in every lane)
+            __syncthreads();
+            if (tid == r) rhs[r] = x;
+            if (tid < r) rhs[tid] -= M[tid][r] * x;
+            __syncthreads();
         }
-        piv_row = bad ? -1 : 0;
+        if (tid == 0) piv_row = bad ? -1 : 0;
     }
     __syncthreads();
     if (bad || piv_row < 0) {
