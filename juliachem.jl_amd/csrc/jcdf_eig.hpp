@@ -684,7 +684,6 @@ __global__ __launch_bounds__(512) void k_sytrd_onehop(double *__restrict__ A, in
                 const int j = g + (have ? cbase + wv : c0) * G;
                 double *col = slab + (size_t)(have ? cbase + wv : c0) * n + r0;
                 const double wj = ws[j - r0], vj = vs[j - r0];
-                const bool send = have && j == r0 + 1;
                 double s0 = 0.0;
                 // four passes' operands are fetched before the first result is stored: the compiler cannot move a load above the
                 // store of the pass before (all of it is one LDS array to it), and a lane's passes would run one LDS latency each
@@ -705,15 +704,20 @@ __global__ __launch_bounds__(512) void k_sytrd_onehop(double *__restrict__ A, in
                         if (ii < m) {
                             const double x0 = cc[u] - (vv[u] * wj + wwv[u] * vj);
                             if (have) col[ii] = x0;
-                            if (ii >= 1) {
-                                s0 += x0 * (ii == 1 ? 1.0 : zz[u] * scale);
-                                if (send) pub(cnb, ii - 1, x0, ctag);
-                            }
+                            if (ii >= 1) s0 += x0 * (ii == 1 ? 1.0 : zz[u] * scale);
                         }
                     }
                 }
                 const double sy = wave_sum(s0);
                 if (ln == 0 && have) pub(ynb, j - (r0 + 1), tau_next * sy, ytag);
+            }
+            // column r0+1 goes out from its owner — by ALL its waves, from the slab the pass above has just updated: published
+            // inside the pass by the one wave that owns the column it was m / 64 store instructions on that wave alone, and every
+            // step has one such workgroup whose lateness the whole grid then waits for in the next round of polls
+            if (r0 + 1 < n && g == (r0 + 1) % G) {         // (uniform over the workgroup)
+                __syncthreads();
+                const double *nxt = slab + (size_t)((r0 + 1) / G) * n + r0;
+                for (int i = 1 + tid; i < m; i += nthr) pub(cnb, i - 1, nxt[i], ctag);
             }
             if (tid == 0 && lastcol <= k + 1) pub(hg + (size_t)((k + 1) & 1) * G, g, 0.0, ytag);     // heartbeat (k+1)
         }
