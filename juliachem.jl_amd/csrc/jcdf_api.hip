@@ -1946,15 +1946,15 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
             const unsigned nmu = (unsigned)lv.nm;
             if (maxm >= 256) {
                 const unsigned gx = (unsigned)((maxm + 3) / 4);                   // 4 roots (64 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
                 hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
             } else if (maxm >= 64) {
                 const unsigned gx = (unsigned)((maxm + 15) / 16);                 // 16 roots (16 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
                 hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
             } else {
                 const unsigned gx = (unsigned)std::max(1, (maxm + 63) / 64);      // 64 roots (4 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
+                hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
                 hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
             }
             {

@@ -395,10 +395,20 @@ __device__ void dc_secular_root(int j, int K, const double *__restrict__ d, cons
     auto eval = [&](int o, double mu, double &psi, double &dpsi, double &phi, double &dphi) {
         double a = 0.0, da = 0.0, b = 0.0, db = 0.0;
         const double dorg = d[o];
-        for (int i = lane; i < K; i += LANES) {
-            const double t = z[i] * dc_recip((d[i] - dorg) - mu);
-            const double zt = z[i] * t;
-            if (i <= j) { a += zt; da += t * t; } else { b += zt; db += t * t; }
+        for (int i0 = lane; i0 < K; i0 += 4 * LANES) {                       // four independent terms at a time (each is a chain of ~10)
+            double t[4], zi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * LANES;
+                const bool in = i < K;
+                zi[u] = in ? z[i] : 0.0;
+                t[u] = zi[u] * dc_recip(in ? (d[i] - dorg) - mu : 1.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double zt = zi[u] * t[u], tt = t[u] * t[u];
+                if (i0 + u * LANES <= j) { a += zt; da += tt; } else { b += zt; db += tt; }
+            }
         }
         psi = rho * lanes_sum<LANES>(a);
         dpsi = rho * lanes_sum<LANES>(da);
@@ -473,9 +483,17 @@ __device__ __forceinline__ void dc_secular_body(const DcMerge *__restrict__ merg
     const int K = dc_ld(Kin + mi);
     const int lane = threadIdx.x % LANES;
     const int rpb = blockDim.x / LANES;                                       // roots per block
+    // the poles and weights of the merge go to LDS once: a root needs ~10 evaluations of the secular function, each a pass over
+    // all of them, and from global memory every pass paid the L2 latency per term (19 us per launch, ~2 us per evaluation)
+    double *sd = dyn_smem, *sz = dyn_smem + K;                                // (2 K doubles <= 2 m: see the launches)
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        sd[i] = dl[mg.xoff + i];
+        sz[i] = zl[mg.xoff + i];
+    }
+    __syncthreads();
     for (int j = vbx * rpb + threadIdx.x / LANES; j < ((K + rpb - 1) / rpb) * rpb; j += vgx * rpb) {
-        // (whole groups stay in the loop together: __shfl needs every lane of the group)
-        if (j < K) dc_secular_root<LANES>(j, K, dl + mg.xoff, zl + mg.xoff, dc_ld(rho_in + mi), lane, org + mg.xoff + j, mu + mg.xoff + j);
+        // (whole groups stay in the loop together: the reductions need every lane of the group)
+        if (j < K) dc_secular_root<LANES>(j, K, sd, sz, dc_ld(rho_in + mi), lane, org + mg.xoff + j, mu + mg.xoff + j);
     }
 }
 
