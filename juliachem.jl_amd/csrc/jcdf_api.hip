@@ -647,6 +647,8 @@ struct DcPlan {
 std::mutex g_dc_mutex;
 std::map<std::pair<int, int64_t>, DcPlan> g_dc_plans;       // (device, n)
 
+constexpr int DC_PREPARE_LDS_MAX = 96 * 1024;            // k_dc_prepare's dynamic LDS (36 bytes per row of a merge)
+
 const DcPlan *dc_plan(int64_t n)
 {
     int dev = 0;
@@ -745,7 +747,7 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_chol_syrk, C128Cfg::SMEM_BYTES);
     set((const void *)k_dc_update_mfma<DcCfg>, DcCfg::SMEM_BYTES);
     set((const void *)k_dc_update_mfma<DcCfg32>, DcCfg32::SMEM_BYTES);
-    set((const void *)k_dc_prepare, 64 * 1024);
+    set((const void *)k_dc_prepare, DC_PREPARE_LDS_MAX);
     set((const void *)k_blas_gemm_tn<BlasTNCfg>, BlasTNCfg::SMEM_BYTES);
     set((const void *)k_blas_gemm_tn<BlasTN64Cfg>, BlasTN64Cfg::SMEM_BYTES);
     set((const void *)k_ns_gemm, BlasTNCfg::SMEM_BYTES);
@@ -1467,6 +1469,10 @@ static int sytrd_groups(int64_t n, bool with_q, size_t *lds_bytes)
     return G;
 }
 
+// largest n of the one-exchange kernel k_sytrd_onehop: 8 columns of a workgroup + 5 vectors in LDS (104 n bytes <= 160 KB),
+// rows of Q in registers (k_sytrd_onehop<48>: n <= 32 * 48)
+constexpr int64_t SYTRD_ONEHOP_MAX_N = 1536;
+
 static int64_t sytrd_granule_bytes(int64_t n)
 {
     // err word (64 B header) + granule pairs: v 2(n+1), y 2n (+ 512 spare); 16 B per pair
@@ -1495,7 +1501,9 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         return JCDF_ERR_INVALID;
     size_t lds = 0;
     const int G = sytrd_groups(n, d_Q != nullptr, &lds);
-    if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // n too large for LDS residency
+    // (n <= SYTRD_ONEHOP_MAX_N runs the one-exchange kernel, whose rows of Q live in registers: the LDS of the two-exchange kernel
+    //  only limits the sizes above)
+    if (n > SYTRD_ONEHOP_MAX_N && lds > 160 * 1024) return JCDF_ERR_INVALID;   // n too large for LDS residency
     hipStream_t st = (hipStream_t)stream;
     char *w = (char *)d_work;
     int *err = (int *)(w + 8);
@@ -1523,9 +1531,9 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     // (with every poll of a thread in flight at once, sub_two_n, the one-exchange kernel also wins at n = 700: 3.86 vs 3.98 ms and
     //  956: 5.86 vs 6.11 ms; with 512 threads — one WAVE per column in the fused pass and per row of Q — it wins wherever its
     //  slabs fit the LDS: whole eigensolve n = 1000 6.53 -> 5.26 ms, n = 1250 9.01 (two exchanges) -> 7.66, n = 1500 13.3)
-    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= 1536;
+    const bool onehop = onehop_env >= 0 ? onehop_env != 0 : n <= SYTRD_ONEHOP_MAX_N;
     if (kstop == 0) return finish();                                     // the whole matrix is the tail (Q starts as the unit matrix there)
-    if (onehop && n <= 1536) {
+    if (onehop && n <= SYTRD_ONEHOP_MAX_N) {
         int G1 = (int)std::max<int64_t>(n >= 400 ? 64 : (n >= 100 ? 32 : (n >= 32 ? 8 : 1)), (n + 7) / 8);   // <= 8 columns each
         if (const char *e = diag_env("JCDF_SYTRD_G1")) G1 = std::max(G1, std::min(256, atoi(e)));                 // diagnostic builds: more workgroups
         const size_t lds1 = (size_t)(((n + G1 - 1) / G1) * n + 5 * n + 32) * 8;
@@ -1546,6 +1554,7 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
 #undef JCDF_ONEHOP
         return finish();
     }
+    if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // (reached below the one-exchange limit only by a diagnostic override)
     if (hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return JCDF_ERR_HIP;
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
@@ -1592,8 +1601,8 @@ int32_t jcdf_keepalive_device(void *stream, int32_t workgroups, int32_t threads,
 int64_t jcdf_sytrd_max_n(int32_t with_q)
 {
     int64_t n = 64;
-    while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;
-    return n;
+    while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;       // the two-exchange kernel (Q rows in LDS)
+    return std::max<int64_t>(n, SYTRD_ONEHOP_MAX_N);                     // the one-exchange kernel (Q rows in registers)
 }
 
 #ifdef JCDF_DIAGNOSTIC
@@ -1933,7 +1942,7 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
         const DcMerge *mg = plan->d_merges + lv.merge_off;
         const int maxm = lv.maxm;
         const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4;
-        if (prep_lds > 64 * 1024) return JCDF_ERR_INVALID;                    // n > ~2300
+        if (prep_lds > DC_PREPARE_LDS_MAX) return JCDF_ERR_INVALID;           // 36 bytes per row of the largest merge: n > ~2700
         static const int fuse_max = diag_env("JCDF_DC_FUSE_MAX") ? atoi(diag_env("JCDF_DC_FUSE_MAX")) : 32;
         if (maxm <= fuse_max) {       // tiny merges: one launch per level instead of six
             hipLaunchKernelGGL(k_dc_merge_small<4>, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,

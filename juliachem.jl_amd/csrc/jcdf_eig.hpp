@@ -359,22 +359,23 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
         const bool next_owner = (k + 1 < kend) && (g == (k + 1) % G);
 
         {   // tau == 0 (nothing to annihilate) runs the same exchange with y = 0: every slot is rewritten every step
-            // ---- y_j = tau * A22[:, j] . v for my columns j > k: 32 lanes per column, SYTRD_CB columns per pass
+            // ---- y_j = tau * A22[:, j] . v for my columns j > k: one 64-lane WAVE per column (as in k_sytrd_onehop: the per-lane
+            //      length of this loop is on the dependent chain of every step; a 32-lane group per column left half the waves idle)
             {
-                const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;      // cpp columns per pass
-                for (int cb = c0; cb < nc; cb += cpp) {
-                    const bool have = cb + ce < nc;
-                    const double *col = slab + (size_t)(have ? cb + ce : c0) * n + (k + 1);
+                const int ln = tid & 63, wv = tid >> 6, nwv = nthr >> 6;      // nwv columns per pass
+                for (int cb = c0; cb < nc; cb += nwv) {
+                    const bool have = cb + wv < nc;
+                    const double *col = slab + (size_t)(have ? cb + wv : c0) * n + (k + 1);
                     double s0 = 0.0, s1 = 0.0;
-                    int i = seg;
-                    for (; i + 32 < m; i += 64) {
+                    int i = ln;
+                    for (; i + 64 < m; i += 128) {
                         s0 += col[i] * vs[i];
-                        s1 += col[i + 32] * vs[i + 32];
+                        s1 += col[i + 64] * vs[i + 64];
                     }
                     if (i < m) s0 += col[i] * vs[i];
-                    const double s = half_sums(s0 + s1);
-                    if (seg == 31 && have) {
-                        const int j = g + (cb + ce) * G;
+                    const double s = wave_sum(s0 + s1);
+                    if (ln == 0 && have) {
+                        const int j = g + (cb + wv) * G;
                         pub(yb, j - (k + 1), tau * s, tag);
                     }
                 }
@@ -384,26 +385,20 @@ __global__ __launch_bounds__(512) void k_sytrd_lower(double *__restrict__ A, int
             // ---- while y travels: Q <- Q H_k on my rows of Q (needs only v_k; same lanes own the same
             //      elements in every step, so no barrier).  Replaces the ormtr back-transformation by one GEMM.
             if (Qout) {
-                const int seg = tid & 31, ce = tid >> 5, cpp = nthr >> 5;
-                for (int rb = 0; rb < nc; rb += cpp) {
-                    const bool have = rb + ce < nc;
-                    double *q = qrow + (size_t)(have ? rb + ce : 0) * n + (k + 1);
+                const int ln = tid & 63, wv = tid >> 6, nwv = nthr >> 6;      // one wave per row of Q
+                for (int rb = 0; rb < nc; rb += nwv) {
+                    const bool have = rb + wv < nc;
+                    double *q = qrow + (size_t)(have ? rb + wv : 0) * n + (k + 1);
                     double s0 = 0.0, s1 = 0.0;
-                    int i = seg;
-                    for (; i + 32 < m; i += 64) {
+                    int i = ln;
+                    for (; i + 64 < m; i += 128) {
                         s0 += q[i] * vs[i];
-                        s1 += q[i + 32] * vs[i + 32];
+                        s1 += q[i + 64] * vs[i + 64];
                     }
                     if (i < m) s0 += q[i] * vs[i];
-                    const double h = half_sums(s0 + s1);
-                    const long long hb = __double_as_longlong(h);
-                    const int lo31 = __builtin_amdgcn_readlane((int)(hb & 0xffffffffLL), 31), hi31 = __builtin_amdgcn_readlane((int)(hb >> 32), 31);
-                    const int lo63 = __builtin_amdgcn_readlane((int)(hb & 0xffffffffLL), 63), hi63 = __builtin_amdgcn_readlane((int)(hb >> 32), 63);
-                    const double tot = (tid & 32) ? __longlong_as_double(((long long)hi63 << 32) | (unsigned)lo63)
-                                                  : __longlong_as_double(((long long)hi31 << 32) | (unsigned)lo31);
-                    const double sc = tau * tot;
+                    const double sc = tau * wave_sum(s0 + s1);
                     if (have)
-                        for (int i2 = seg; i2 < m; i2 += 32) q[i2] -= sc * vs[i2];
+                        for (int i2 = ln; i2 < m; i2 += 64) q[i2] -= sc * vs[i2];
                 }
             }
             SYTRD_TICK(4);                                // Q accumulation
