@@ -226,7 +226,8 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
  * padded GEMM operand), accumulated inside the chip-wide kernel while the
  * reflectors travel between workgroups (the last 128 reflectors by one row-parallel launch), so the
  * eigenvectors of A are ONE GEMM Q*Z away (instead of LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
- * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above). */
+ * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above):
+ * 1536 with Q (the one-exchange kernel: rows of Q in registers), ~2040 without. */
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
