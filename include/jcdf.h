@@ -18,9 +18,11 @@
  *     and never retains a host pointer (Julia GC may move/free it afterwards).
  *   - one handle == one HIP device == one auxiliary-index shard (the reference's
  *     "global device id", GPUDF.jl:1026-1056).  Handles are independent; the
- *     caller sums the per-shard Fock matrices (reference: host axpy
- *     GPUDF.jl:267-277 and MPI.Allreduce! DensityFitting.jl:68-71; here: RCCL
- *     all-reduce on the device buffer returned by jcdf_fock_build_device).
+ *     per-shard Fock matrices are summed either by a group of handles — all devices of one
+ *     process, summed ON THE DEVICES over RCCL / peer-mapped buffers: the end of this
+ *     header — or by the caller (reference: host axpy GPUDF.jl:267-277 and
+ *     MPI.Allreduce! DensityFitting.jl:68-71; one process per GPU: RCCL all-reduce on
+ *     the device buffer returned by jcdf_fock_build_device).
  *   - calls on one handle must come from one host thread at a time.
  */
 #ifndef JCDF_H
@@ -319,6 +321,87 @@ int32_t jcdf_kernel_stats(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_rec
  * still running when its successor was enqueued is left out of the sums (and of *n_builds). */
 int32_t jcdf_kernel_stats_total(jcdf_handle *h, jcdf_kernel_stat *out, int32_t max_records, int64_t *n_builds, double *fock_seconds,
                                 int32_t reset);
+
+/* ---- multi-device group: all devices of one process behind ONE call, F reduced ON THE DEVICES ---------------
+ * Replaces, for scf flag num_devices > 1: the one-task-per-device loop (GPUDF.jl:188-193, DenseGPUDF.jl:83-86), the
+ * D2H of every device's F + the host axpy! over devices (GPUDF.jl:267-277, DenseGPUDF.jl:131-137) and, inside a node,
+ * the MPI.Allreduce! of the partial Fock matrices (DensityFitting.jl:68-71).  A group owns n handles (member i = aux
+ * shard i on device_ids[i]); ONE host thread drives them all:
+ *   - C_occ goes up ONCE (H2D to member 0) and reaches the other devices device-to-device (hipMemcpyPeerAsync over xGMI);
+ *   - every member runs the same kernels as jcdf_fock_build on its shard, concurrently, each on its own stream;
+ *   - the n partial Fock matrices are summed on the devices by a reduce-scatter over slices of the N*N elements
+ *     (jcdf_group_reduce_plan), transport "rccl": ncclReduceScatter of librccl.so.1 (dlopen'ed; one communicator per
+ *     member, ncclCommInitAll) — transport "peer": a hand-written kernel on every member that sums its slice from all
+ *     members' peer-mapped buffers in FIXED member order (bit-reproducible; needs hipDeviceEnablePeerAccess);
+ *   - the reduced slices leave the devices as ONE pass of D2H copies into F_out (slice i from device i: N*N doubles in
+ *     total, each device over its own PCIe link), or, for a device-resident caller, are gathered on member 0.
+ * "auto" (default) = "rccl" when the members are n > 1 distinct devices and librccl.so.1 can be loaded, else "peer".
+ * Several members MAY share a device (several aux shards per GPU; also how the group logic is tested on one GPU) —
+ * only the "peer" transport serves such a group (RCCL refuses duplicate devices).  A transport that cannot be set up
+ * or fails returns JCDF_ERR_HIP / JCDF_ERR_INVALID with the reason in jcdf_group_last_error: there is NO silent
+ * fallback to a host-side reduce.  Calls on one group must come from one host thread at a time. */
+typedef struct jcdf_group jcdf_group;
+#define JCDF_GROUP_MAX_DEVICES 16
+
+/* Group-level times of the last jcdf_group_fock_build* in seconds (device events on member streams / the host clock). */
+typedef struct jcdf_group_timings {
+    double bcast_time;     /* C_occ: H2D to member 0 + device-to-device copies to the others   GPUDF.jl:206 (one H2D per device there) */
+    double build_time;     /* longest member Fock build (device events)                         "GPU_-N-_fock_time-"   */
+    double reduce_time;    /* device-side reduce-scatter of F (longest member)                 replaces axpy! GPUDF.jl:273-276 */
+    double d2h_time;       /* the one pass of slice copies into F_out (host entry) / gather on member 0 (device entry) */
+    double total_time;     /* host clock around the whole call                                  "total_fock_gpu_time-" */
+} jcdf_group_timings;
+
+/* device_ids[i] = HIP device of member i (0 <= n_devices <= JCDF_GROUP_MAX_DEVICES).  JCDF_ERR_NO_DEVICE as jcdf_create. */
+int32_t jcdf_group_create(jcdf_group **out, int32_t n_devices, const int32_t *device_ids);
+int32_t jcdf_group_destroy(jcdf_group *g);
+/* Message of the last failing call on g (g == NULL: last jcdf_group_create failure). */
+const char *jcdf_group_last_error(const jcdf_group *g);
+int32_t jcdf_group_size(const jcdf_group *g);
+/* Member i's handle, BORROWED (never jcdf_destroy it): for the per-handle calls that have no group form — jcdf_set_tuning,
+ * jcdf_get_V/W/B, jcdf_set_B, jcdf_kernel_stats, jcdf_device_bytes ...  NULL when i is out of range. */
+jcdf_handle *jcdf_group_handle(jcdf_group *g, int32_t i);
+/* "auto" | "rccl" | "peer" (before the first Fock build or between builds).  JCDF_ERR_INVALID for an unknown name or
+ * "rccl" on a group with a shared device; JCDF_ERR_HIP when librccl.so.1 / peer access is not available. */
+int32_t jcdf_group_set_transport(jcdf_group *g, const char *name);
+/* Transport in effect, e.g. "rccl 2.22.3 (librccl.so.1, 8 ranks)" or "peer (8 members, fixed-order slice sums)". */
+const char *jcdf_group_transport(const jcdf_group *g);
+/* The reduce-scatter partition of `count` = N*N elements over n members, exported for tests (pure host code):
+ * offsets[i] .. offsets[i+1] is member i's slice (equal chunks of a multiple of 256 elements, the last ones clipped to
+ * count; offsets has n + 1 entries).  Returns the chunk length, or -1 on bad arguments. */
+int64_t jcdf_group_reduce_plan(int64_t count, int32_t n, int64_t *offsets);
+
+/* jcdf_configure on every member: shard_q0[i] .. shard_q0[i+1] = member i's aux function range (n + 1 entries,
+ * ascending and contiguous: calculate_device_ranges_GPU, GPUDF.jl:1026-1056; dense path static_load_rank_indicies
+ * per device, DenseGPUDF.jl:228-236).  One process: shard_q0[0] = 0 and shard_q0[n] = Q_total; with several ranks a
+ * group holds its rank's devices, a contiguous part of the auxiliary basis, and its F is that part's partial sum.
+ * jcdf_set_tuning on the members and jcdf_group_set_exchange_screening go before it. */
+int32_t jcdf_group_configure(jcdf_group *g, int64_t N, int64_t Q_total, const int64_t *shard_q0, int64_t n_occ,
+                             int64_t P, const int64_t *pq_p, const int64_t *pq_q);
+int32_t jcdf_group_set_exchange_screening(jcdf_group *g, int64_t n_blocks);
+/* Metric: potrf + trtri ONCE, on member 0's device ("always do J_AB_INV on the first device", DenseGPUDF.jl:177-193);
+ * the other members take their rows of L^-1 device-to-device (reference: D2H + one H2D per device, DenseGPUDF.jl:221-227). */
+int32_t jcdf_group_set_metric(jcdf_group *g, const double *J2c);
+/* Three-centre rows [s0,s1) (as jcdf_push_three_center): ONE H2D, to the first member that needs the block; the other
+ * members read it device-to-device (reference: one H2D of the block per device, DenseGPUDF.jl:258-262, GPUDF.jl:864-866).
+ * Members whose rows lie above the block (s0 >= q1) are skipped: L^-1 is lower triangular.  T may also be device memory
+ * of any device of the process (the first copy is a hipMemcpyDefault): a block received over RCCL is pushed as it is. */
+int32_t jcdf_group_push_three_center(jcdf_group *g, int64_t s0, int64_t s1, const double *T);
+/* H on member 0 only (GPUDF.jl:158-161, 221-225); NULL: no member adds H. */
+int32_t jcdf_group_set_core_hamiltonian(jcdf_group *g, const double *H);
+
+/* One Fock build over all members: C_occ N x n_occ column-major host, F_out N x N host, fully overwritten with
+ * sum_i (2 J_i - K_i) (+ H) — the contract of scf_data.two_electron_fock after the device loop and host reduce of
+ * GPUDF.jl:188-277.  t: n_devices entries (member i's device timings) or NULL; gt may be NULL. */
+int32_t jcdf_group_fock_build(jcdf_group *g, const double *C_occ, double *F_out, jcdf_timings *t, jcdf_group_timings *gt);
+/* The same for a device-resident caller on member 0's device (as jcdf_fock_build_device_ld): orbital i at
+ * d_C_occ + ldc * i, column p of the REDUCED F at d_F + ldf * p.  Work is ordered behind `stream` (a hipStream_t of
+ * member 0's device; NULL = member 0's stream) and the result is complete on that stream when the call returns
+ * (NOT synchronised): the SCF loop of a single process can keep its replicated part on one device and still shard the
+ * Fock build over all of them. */
+int32_t jcdf_group_fock_build_device_ld(jcdf_group *g, const double *d_C_occ, int64_t ldc, double *d_F, int64_t ldf, void *stream);
+/* Blocks until the last group build has finished on every member; fills t (n entries) / gt like jcdf_group_fock_build. */
+int32_t jcdf_group_synchronize(jcdf_group *g, jcdf_timings *t, jcdf_group_timings *gt);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ Layout:  csrc/   HIP kernels + C ABI (include/jcdf.h)  -> lib/libjcdf_hip.so
 """
 from . import _lib
 from ._lib import JCDFError, LIB_PATH
-from .df import (JCDFHandle, JCTC, JCTiming, JCTiming_GPUkey, JCTiming_key, SCFData, SCFGPUData_hip,
+from .df import (JCDFHandle, JCDFGroup, group_reduce_plan, JCTC, JCTiming, JCTiming_GPUkey, JCTiming_key, SCFData, SCFGPUData_hip,
                  SCFOptions, ScreeningData, Basis, Shell, CalculationBasisSets, DFIntegralEngine,
                  TensorIntegralEngine, basis_from_shell_sizes, create_jctiming, create_scf_options,
                  df_rhf_fock_build, df_rhf_fock_build_GPU, get_default_gpu_data_hip,

@@ -30,6 +30,10 @@ class jcdf_timings(C.Structure):
         "H_add_time", "copy_J_time", "fock_time", "copy_time")]
 
 
+class jcdf_group_timings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("bcast_time", "build_time", "reduce_time", "d2h_time", "total_time")]
+
+
 class jcdf_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("seconds", C.c_double), ("flops", C.c_double),
                 ("alg_flops", C.c_double), ("alg_bytes", C.c_double)]
@@ -89,6 +93,23 @@ PROTOTYPES = {
     "jcdf_device_bytes": (_I64, [_P]),
     "jcdf_kernel_stats": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32]),
     "jcdf_kernel_stats_total": (C.c_int32, [_P, C.POINTER(jcdf_kernel_stat), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
+    # multi-device group (all devices of one process behind one call; F reduced on the devices)
+    "jcdf_group_create": (C.c_int32, [C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32)]),
+    "jcdf_group_destroy": (C.c_int32, [_P]),
+    "jcdf_group_last_error": (C.c_char_p, [_P]),
+    "jcdf_group_size": (C.c_int32, [_P]),
+    "jcdf_group_handle": (_P, [_P, C.c_int32]),
+    "jcdf_group_set_transport": (C.c_int32, [_P, C.c_char_p]),
+    "jcdf_group_transport": (C.c_char_p, [_P]),
+    "jcdf_group_reduce_plan": (_I64, [_I64, C.c_int32, C.POINTER(C.c_int64)]),
+    "jcdf_group_configure": (C.c_int32, [_P, _I64, _I64, C.POINTER(C.c_int64), _I64, _I64, _P, _P]),
+    "jcdf_group_set_exchange_screening": (C.c_int32, [_P, _I64]),
+    "jcdf_group_set_metric": (C.c_int32, [_P, _P]),
+    "jcdf_group_push_three_center": (C.c_int32, [_P, _I64, _I64, _P]),
+    "jcdf_group_set_core_hamiltonian": (C.c_int32, [_P, _P]),
+    "jcdf_group_fock_build": (C.c_int32, [_P, _P, _P, C.POINTER(jcdf_timings), C.POINTER(jcdf_group_timings)]),
+    "jcdf_group_fock_build_device_ld": (C.c_int32, [_P, _P, _I64, _P, _I64, _P]),
+    "jcdf_group_synchronize": (C.c_int32, [_P, C.POINTER(jcdf_timings), C.POINTER(jcdf_group_timings)]),
 }
 
 # entry points of DIAGNOSTIC builds only (csrc/jcdf_diag.h; tools/build_diag.sh + JCDF_LIB_PATH): bound when present

@@ -619,12 +619,12 @@ int32_t upload_linv(jcdf_handle *h, const double *Linv)
 }
 
 // dLinv[r][s] = V[s][q0 + r] straight from the device factorisation (V = L^-T, row-major upper)
-int32_t upload_linv_from_device(jcdf_handle *h, const CholBuffers &w)
+int32_t upload_linv_from_device(jcdf_handle *h, const double *V, int64_t ldv)
 {
     int32_t rc = alloc_linv(h);
     if (rc) return rc;
     dim3 grid((unsigned)((h->Ql + 31) / 32), (unsigned)((h->Qtot + 31) / 32));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, w.V, w.ld, h->q0, h->Ql, h->Qtot, h->dLinv, h->ldl);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, V, ldv, h->q0, h->Ql, h->Qtot, h->dLinv, h->ldl);
     JCDF_HIP(h, hipGetLastError());
     JCDF_HIP(h, hipStreamSynchronize(h->stream));
     h->have_metric = true;
@@ -777,7 +777,7 @@ hipError_t ensure_device_attributes()
 // ============================================================================
 extern "C" {
 
-int32_t jcdf_abi_version(void) { return 1001; }
+int32_t jcdf_abi_version(void) { return 1002; }
 
 const char *jcdf_last_error(const jcdf_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1220,7 +1220,7 @@ int32_t jcdf_set_metric(jcdf_handle *h, const double *J2c)
     if (e != hipSuccess) return fail(h, JCDF_ERR_HIP, std::string("jcdf_set_metric: ") + hipGetErrorString(e));
     if (info != 0)
         return fail(h, JCDF_ERR_NOT_SPD, "jcdf_set_metric: (P|Q) not positive definite at pivot " + std::to_string(info));
-    return upload_linv_from_device(h, w);
+    return upload_linv_from_device(h, w.V, w.ld);
 }
 
 int32_t jcdf_device_potrf_trtri(int32_t device_id, double *A, int64_t n)
@@ -2215,3 +2215,5 @@ int32_t jcdf_kernel_stats_total(jcdf_handle *h, jcdf_kernel_stat *out, int32_t m
 }
 
 }  // extern "C"
+
+#include "jcdf_group.hpp"          // the multi-device group (jcdf_group_*)

@@ -27,7 +27,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import JCDFError, jcdf_kernel_stat, jcdf_timings
+from ._lib import JCDFError, jcdf_group_timings, jcdf_kernel_stat, jcdf_timings
 
 
 # --------------------------------------------------------------------------
@@ -220,6 +220,7 @@ class SCFGPUData_hip(SCFGPUData):
 
     def __init__(self) -> None:
         self.handles: List["JCDFHandle"] = []
+        self.group: Optional["JCDFGroup"] = None      # num_devices > 1: the handles are the group's members
         self.device_Q_range_lengths: List[int] = []
         self.device_Q_indices: List[range] = []
         self.number_of_devices_used: int = 0
@@ -228,6 +229,9 @@ class SCFGPUData_hip(SCFGPUData):
         for h in self.handles:
             h.close()
         self.handles = []
+        if self.group is not None:
+            self.group.close()
+            self.group = None
 
 
 def get_default_gpu_data_hip() -> SCFGPUData_hip:
@@ -333,12 +337,16 @@ def _f64(a: np.ndarray, order: str = "F") -> np.ndarray:
 class JCDFHandle:
     """One HIP device == one aux shard (include/jcdf.h)."""
 
-    def __init__(self, device_id: int = 0) -> None:
+    def __init__(self, device_id: int = 0, _borrowed: Optional[int] = None) -> None:
         self._lib = _lib.load()
-        hp = C.c_void_p()
-        rc = self._lib.jcdf_create(C.byref(hp), int(device_id))
-        if rc != 0:
-            raise JCDFError(rc, (self._lib.jcdf_last_error(None) or b"").decode())
+        self._owned = _borrowed is None
+        if _borrowed is not None:                    # a member of a JCDFGroup: the group destroys it
+            hp = C.c_void_p(_borrowed)
+        else:
+            hp = C.c_void_p()
+            rc = self._lib.jcdf_create(C.byref(hp), int(device_id))
+            if rc != 0:
+                raise JCDFError(rc, (self._lib.jcdf_last_error(None) or b"").decode())
         self._h = hp
         self.device_id = device_id
         self.N = self.o = self.Ql = self.P = 0
@@ -349,7 +357,8 @@ class JCDFHandle:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.jcdf_destroy(self._h)
+            if self._owned:
+                self._lib.jcdf_destroy(self._h)
             self._h = None
 
     def __del__(self) -> None:
@@ -495,6 +504,121 @@ def _kernel_stats_total(self, reset: bool = False):
 JCDFHandle.kernel_stats_total = _kernel_stats_total
 
 
+class JCDFGroup:
+    """All devices of this process behind one call (include/jcdf.h, jcdf_group_*): member i = aux shard i on
+    device_ids[i]; C_occ goes up once, the partial Fock matrices are summed ON THE DEVICES (RCCL reduce-scatter or the
+    library's peer-mapped slice sums) and F comes down once — instead of the reference's one task, one H2D, one D2H per
+    device and a host axpy! (GPUDF.jl:188-193, 267-277)."""
+
+    def __init__(self, device_ids: Sequence[int]) -> None:
+        self._lib = _lib.load()
+        ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        gp = C.c_void_p()
+        rc = self._lib.jcdf_group_create(C.byref(gp), len(device_ids), ids)
+        if rc != 0:
+            raise JCDFError(rc, (self._lib.jcdf_group_last_error(None) or b"").decode())
+        self._g = gp
+        self.device_ids = [int(d) for d in device_ids]
+        self.n = len(self.device_ids)
+        self.members = [JCDFHandle(d, _borrowed=self._lib.jcdf_group_handle(gp, i)) for i, d in enumerate(self.device_ids)]
+        self.N = self.o = self.P = self.Qtot = 0
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise JCDFError(rc, (self._lib.jcdf_group_last_error(self._g) or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()                             # borrowed: forgets the pointer
+            self._lib.jcdf_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_transport(self, name: str) -> None:
+        """"auto" | "rccl" | "peer" """
+        self._check(self._lib.jcdf_group_set_transport(self._g, name.encode()))
+
+    def transport(self) -> str:
+        return (self._lib.jcdf_group_transport(self._g) or b"").decode()
+
+    def set_exchange_screening(self, n_blocks: int) -> None:
+        self._check(self._lib.jcdf_group_set_exchange_screening(self._g, int(n_blocks)))
+
+    def configure(self, N: int, Q_total: int, shard_q0: Sequence[int], n_occ: int,
+                  pq_p: Optional[np.ndarray] = None, pq_q: Optional[np.ndarray] = None) -> None:
+        if len(shard_q0) != self.n + 1:
+            raise JCDFError(1, "shard_q0 needs n_devices + 1 entries")
+        if pq_p is None:
+            P, pp, pq = N * N, None, None
+        else:
+            self._pq_p = np.ascontiguousarray(pq_p, dtype=np.int64)
+            self._pq_q = np.ascontiguousarray(pq_q, dtype=np.int64)
+            P, pp, pq = self._pq_p.size, self._pq_p.ctypes.data, self._pq_q.ctypes.data
+        q0 = (C.c_int64 * (self.n + 1))(*[int(x) for x in shard_q0])
+        self._check(self._lib.jcdf_group_configure(self._g, N, Q_total, q0, n_occ, P, pp, pq))
+        self.N, self.o, self.P, self.Qtot = N, n_occ, P, Q_total
+        for i, m in enumerate(self.members):
+            m.N, m.o, m.P, m.Qtot = N, n_occ, P, Q_total
+            m.q0, m.q1 = int(shard_q0[i]), int(shard_q0[i + 1])
+            m.Ql = m.q1 - m.q0
+
+    def set_metric(self, J2c: np.ndarray) -> None:
+        a = _f64(J2c)
+        assert a.shape == (self.Qtot, self.Qtot)
+        self._check(self._lib.jcdf_group_set_metric(self._g, a.ctypes.data))
+
+    def push_three_center(self, s0: int, s1: int, T: np.ndarray) -> None:
+        a = _f64(T)
+        assert a.shape == (s1 - s0, self.P), (a.shape, (s1 - s0, self.P))
+        self._check(self._lib.jcdf_group_push_three_center(self._g, s0, s1, a.ctypes.data))
+
+    def push_three_center_device(self, s0: int, s1: int, d_ptr: int) -> None:
+        """the same entry point: the library copies with hipMemcpyDefault, so T may live on any device of the process"""
+        self._check(self._lib.jcdf_group_push_three_center(self._g, s0, s1, d_ptr))
+
+    def set_core_hamiltonian(self, H: Optional[np.ndarray]) -> None:
+        if H is None:
+            self._check(self._lib.jcdf_group_set_core_hamiltonian(self._g, None))
+        else:
+            a = _f64(H)
+            assert a.shape == (self.N, self.N)
+            self._check(self._lib.jcdf_group_set_core_hamiltonian(self._g, a.ctypes.data))
+
+    def fock_build(self, C_occ: np.ndarray) -> Tuple[np.ndarray, List[jcdf_timings], jcdf_group_timings]:
+        c = _f64(C_occ)
+        if c.shape != (self.N, self.o):
+            raise JCDFError(1, "C_occ has shape %s, expected (N, n_occ) = %s" % (c.shape, (self.N, self.o)))
+        F = np.empty((self.N, self.N), dtype=np.float64, order="F")
+        t = (jcdf_timings * self.n)()
+        gt = jcdf_group_timings()
+        self._check(self._lib.jcdf_group_fock_build(self._g, c.ctypes.data, F.ctypes.data, t, C.byref(gt)))
+        return F, list(t), gt
+
+    def fock_build_device_ld(self, d_C_occ: int, ldc: int, d_F: int, ldf: int, stream: int = 0) -> None:
+        self._check(self._lib.jcdf_group_fock_build_device_ld(self._g, d_C_occ, int(ldc), d_F, int(ldf), stream or None))
+
+    def synchronize(self) -> Tuple[List[jcdf_timings], jcdf_group_timings]:
+        t = (jcdf_timings * self.n)()
+        gt = jcdf_group_timings()
+        self._check(self._lib.jcdf_group_synchronize(self._g, t, C.byref(gt)))
+        return list(t), gt
+
+
+def group_reduce_plan(count: int, n: int) -> Tuple[int, List[int]]:
+    """jcdf_group_reduce_plan: (chunk, n + 1 slice offsets of the N*N elements) — pure host code of the library"""
+    off = (C.c_int64 * (n + 1))()
+    chunk = int(_lib.load().jcdf_group_reduce_plan(int(count), int(n), off))
+    if chunk < 0:
+        raise JCDFError(1, "jcdf_group_reduce_plan: bad arguments")
+    return chunk, [int(x) for x in off]
+
+
 def lapack_potrf_trtri(J2c: np.ndarray) -> np.ndarray:
     """L^-1 exactly as the reference forms it on the host: LAPACK.potrf!('L') + trtri!('L','N')
     (GPUDF.jl:890-891, DensityFitting.jl:137-140), through scipy's LAPACK.  Upper triangle zeroed
@@ -596,55 +720,81 @@ def _comm() -> Tuple[int, int, Any]:
 # the operator
 # --------------------------------------------------------------------------
 def calculate_B_GPU(scf_data: SCFData, engine: DFIntegralEngine, two_center_integrals: np.ndarray,
-                    num_devices: int, basis_sets: CalculationBasisSets, jc_timing: JCTiming) -> None:
-    """B = L^-1 (Q|pq) on the devices (GPUDF.jl:828-1008).  potrf/trtri on the
-    device (reference: host LAPACK at :890-891, cuSOLVER at DenseGPUDF.jl:185-193); every T row block s is produced by its owner and pushed to
-    every handle r with rows_r >= rows_s (L^-1 lower triangular, SURVEY 3.4);
-    across processes the block travels by broadcast (reference: host-staged
-    MPI.Send/Recv!, :918-997)."""
+                    num_devices: int, basis_sets: CalculationBasisSets, jc_timing: JCTiming,
+                    exchange_stats: Optional[dict] = None) -> None:
+    """B = L^-1 (Q|pq) on the devices (GPUDF.jl:828-1008).  potrf/trtri on the device (reference: host LAPACK at
+    :890-891, cuSOLVER at DenseGPUDF.jl:185-193) — with num_devices > 1 once, on the group's first device.  Every T row
+    block s is produced by its owner and accumulated on every shard r with rows_r >= rows_s (L^-1 lower triangular).
+    Across processes the blocks travel point-to-point, block s only to the ranks behind it
+    (`engine.exchange_three_center_blocks`: RCCL send / recv on device tensors with the nccl backend, host tensors with
+    gloo) — the reference stages every block to every rank through the host (MPI.Send/Recv!, :918-997)."""
     rank, n_ranks, dist = _comm()
     gd: SCFGPUData_hip = scf_data.gpu_data
     ranges = calculate_device_ranges_GPU(num_devices, n_ranks, basis_sets)
     gd.device_Q_indices = ranges
     gd.device_Q_range_lengths = [len(r) for r in ranges]
+    sd = scf_data.screening_data
     t0 = time.perf_counter()
-    for h in gd.handles:                 # potrf + trtri on each device (DenseGPUDF.jl:185-193 placement)
-        h.set_metric(two_center_integrals)
+    if gd.group is not None:
+        gd.group.set_metric(two_center_integrals)              # potrf + trtri once, L^-1 rows device-to-device
+    else:
+        for h in gd.handles:
+            h.set_metric(two_center_integrals)
     jc_timing.timings[JCTC.form_J_AB_inv_time] = time.perf_counter() - t0
+
+    def push_host(s0: int, s1: int, T: np.ndarray) -> None:
+        if gd.group is not None:
+            gd.group.push_three_center(s0, s1, T)              # ONE H2D, the other members fetch device-to-device
+        else:
+            for h in gd.handles:
+                h.push_three_center(s0, s1, T)
+
     t_eri = 0.0
     t0 = time.perf_counter()
-    for g, rows in enumerate(ranges):
-        owner, dev = divmod(g, num_devices)
-        if len(rows) == 0:
-            continue
-        T = None
-        if owner == rank:
+    if n_ranks == 1:
+        for rows in ranges:
             t1 = time.perf_counter()
-            T = engine.calculate_three_center_integrals(rows, scf_data.screening_data)
+            T = engine.calculate_three_center_integrals(rows, sd)
             t_eri += time.perf_counter() - t1
-        if n_ranks > 1:
-            import torch
-            buf = torch.empty((len(rows) * scf_data.screening_data.screened_indices_count,),
-                              dtype=torch.float64) if T is None else torch.from_numpy(
-                np.asfortranarray(T).reshape(-1, order="F").copy())
-            dev_t = _bcast_tensor(buf, owner, dist)
-            T = dev_t.numpy().reshape((len(rows), -1), order="F")
-        for h in gd.handles:
-            h.push_three_center(rows.start, rows.stop, T)
+            push_host(rows.start, rows.stop, T)
+    else:
+        import torch
+        from .engine import exchange_three_center_blocks
+        # this rank's rows = the union of its devices' (contiguous) shards; its own T block, (rows, P) column-major, flat
+        rank_ranges = [range(ranges[r * num_devices].start, ranges[r * num_devices + num_devices - 1].stop) for r in range(n_ranks)]
+        own = rank_ranges[rank]
+        t1 = time.perf_counter()
+        T_own = np.asfortranarray(engine.calculate_three_center_integrals(own, sd))
+        t_eri += time.perf_counter() - t1
+        P = sd.screened_indices_count
+        on_device = dist.get_backend() == "nccl"
+        flat = torch.from_numpy(T_own.reshape(-1, order="F"))
+        if on_device:
+            dev0 = torch.device("cuda", gd.handles[0].device_id)
+            flat = flat.to(dev0)
+
+        def push(s0: int, s1: int, chunk) -> None:
+            if on_device:
+                torch.cuda.synchronize(chunk.device)
+                if gd.group is not None:
+                    gd.group.push_three_center_device(s0, s1, chunk.data_ptr())
+                else:
+                    for h in gd.handles:
+                        local = chunk if chunk.device.index == h.device_id else chunk.to(torch.device("cuda", h.device_id))
+                        h.push_three_center_device(s0, s1, local.data_ptr())
+            else:
+                push_host(s0, s1, chunk.numpy().reshape((s1 - s0, P), order="F"))
+
+        alloc = (lambda n: torch.empty(n, dtype=torch.float64, device=dev0)) if on_device else (lambda n: torch.empty(n, dtype=torch.float64))
+        block = max(16, ((1 << 28) // max(P, 1)) // 16 * 16)
+        stats: dict = {}
+        exchange_three_center_blocks(rank_ranges, rank, n_ranks, dist, flat, alloc, push, block=block, stats=stats)
+        if exchange_stats is not None:
+            exchange_stats.update(stats)
+        jc_timing.non_timing_data["B_exchange_doubles_sent"] = str(stats.get("sent", 0))
+        jc_timing.non_timing_data["B_exchange_doubles_received"] = str(stats.get("received", 0))
     jc_timing.timings[JCTC.B_time] = time.perf_counter() - t0 - t_eri
     jc_timing.timings[JCTC.three_eri_time] = t_eri
-
-
-def _bcast_tensor(buf, src: int, dist):
-    """Broadcast a CPU tensor; with the nccl (= RCCL) backend it is staged through
-    this rank's device, with gloo it stays on the host."""
-    import torch
-    if dist.get_backend() == "nccl":
-        d = buf.cuda()
-        dist.broadcast(d, src)
-        return d.cpu()
-    dist.broadcast(buf, src)
-    return buf
 
 
 def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEngine,
@@ -654,7 +804,9 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
                           force_dense: bool = False) -> None:
     """Signature and side effects of df_rhf_fock_build_GPU! (GPUDF.jl:11-14):
     scf_data.two_electron_fock <- this process's sum over its devices of
-    2J - K (+ H on rank 0, device 1)."""
+    2J - K (+ H on rank 0, device 1).  num_devices > 1: the devices are one `JCDFGroup` — C_occ uploaded once, the
+    partial Fock matrices summed on the devices, one pass of D2H (reference: a task, an H2D and a D2H per device and a
+    host axpy!, GPUDF.jl:188-193, 206, 267-277)."""
     rank, n_ranks, _ = _comm()
     num_devices = scf_options.num_devices
     gd = scf_data.gpu_data
@@ -677,31 +829,44 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
         ranges = calculate_device_ranges_GPU(num_devices, n_ranks, basis_sets)
         pq = (None, None) if mask is None else packed_pq_lists(sd)
         gd.close()
-        for dev in range(num_devices):
-            rows = ranges[rank * num_devices + dev]
-            if len(rows) == 0:
-                raise JCDFError(1, "more devices than auxiliary shells: empty shard")
-            h = JCDFHandle(_physical_device(dev if n_ranks == 1 else _local_device(dev, num_devices)))
+        local = ranges[rank * num_devices:(rank + 1) * num_devices]
+        if any(len(r) == 0 for r in local):
+            raise JCDFError(1, "more devices than auxiliary shells: empty shard")
+        devices = [_physical_device(dev if n_ranks == 1 else _local_device(dev, num_devices)) for dev in range(num_devices)]
+        if num_devices > 1:
+            g = JCDFGroup(devices)
+            g.set_exchange_screening(exchange_screen_blocks(scf_options))
+            # this rank's devices hold a contiguous part of the auxiliary basis (global device id = rank * num_devices + dev)
+            g.configure(n, scf_data.A, [r.start for r in local] + [local[-1].stop], n_occ, pq[0], pq[1])
+            g.set_core_hamiltonian(H if rank == 0 else None)                  # member 0 only (GPUDF.jl:158-161)
+            gd.group = g
+            gd.handles = list(g.members)
+        else:
+            h = JCDFHandle(devices[0])
             h.set_exchange_screening(exchange_screen_blocks(scf_options))
-            h.configure(n, scf_data.A, rows.start, rows.stop, n_occ, pq[0], pq[1])
-            h.set_core_hamiltonian(H if (rank == 0 and dev == 0) else None)   # GPUDF.jl:158-161
+            h.configure(n, scf_data.A, local[0].start, local[0].stop, n_occ, pq[0], pq[1])
+            h.set_core_hamiltonian(H if rank == 0 else None)                  # GPUDF.jl:158-161
             gd.handles.append(h)
         calculate_B_GPU(scf_data, eng, two_center, num_devices, basis_sets, jc_timing)
         jc_timing.non_timing_data[JCTC.contraction_algorithm] = "dense hip" if mask is None else "screened hip"
         jc_timing.non_timing_data[JCTC.GPU_num_devices] = str(num_devices)
+        if gd.group is not None:
+            jc_timing.non_timing_data["GPU_reduce_transport"] = gd.group.transport()
         for dev, h in enumerate(gd.handles):
             jc_timing.non_timing_data[JCTiming_GPUkey(JCTC.GPU_data_size_MB, dev + 1)] = str(h.device_bytes() / 1024 ** 2)
 
     t0 = time.perf_counter()
-    total = None
-    per_dev: List[jcdf_timings] = []
-    for h in gd.handles:                       # all devices of this process work concurrently (GPUDF.jl:188-193)
-        h.fock_build_begin(occupied_orbital_coefficients)
-    for h in gd.handles:
-        F, t = h.fock_build_finish()
-        per_dev.append(t)
-        total = F if total is None else total + F          # host reduce over devices, GPUDF.jl:273-276
-    scf_data.two_electron_fock = total
+    if gd.group is not None:
+        # all devices behind one call; the sum over devices happens on the devices
+        F, per_dev, gt = gd.group.fock_build(occupied_orbital_coefficients)
+        scf_data.two_electron_fock = F
+        copy_reduce = gt.bcast_time + gt.reduce_time + gt.d2h_time
+        jc_timing.non_timing_data["GPU_reduce_transport"] = gd.group.transport()
+    else:
+        F, t = gd.handles[0].fock_build(occupied_orbital_coefficients)
+        per_dev = [t]
+        scf_data.two_electron_fock = F
+        copy_reduce = t.copy_time
     jc_timing.timings[JCTiming_key(JCTC.total_fock_gpu_time, iteration)] = time.perf_counter() - t0
     for dev, t in enumerate(per_dev, start=1):
         for key, val in ((JCTC.GPU_W_time, t.W_time), (JCTC.GPU_V_time, t.V_time), (JCTC.GPU_J_time, t.J_time),
@@ -714,7 +879,7 @@ def df_rhf_fock_build_GPU(scf_data: SCFData, jeri_engine_thread_df: DFIntegralEn
                       (JCTC.J_time, "J_time"), (JCTC.fock_time, "fock_time")):
         jc_timing.timings[JCTiming_key(key, iteration)] = max(getattr(t, attr) for t in per_dev)
     jc_timing.timings[JCTiming_GPUkey(JCTC.GPU_H_add_time, 1, iteration)] = per_dev[0].H_add_time
-    jc_timing.timings[JCTiming_key(JCTC.fock_gpu_cpu_copy_reduce_time, iteration)] = max(t.copy_time for t in per_dev)
+    jc_timing.timings[JCTiming_key(JCTC.fock_gpu_cpu_copy_reduce_time, iteration)] = copy_reduce
 
 
 def _physical_device(index: int) -> int:

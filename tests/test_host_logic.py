@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export %s" % n
         assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
-    assert _lib.load().jcdf_abi_version() == 1001
+    assert _lib.load().jcdf_abi_version() == 1002
 
 
 def test_library_exports_nothing_but_the_declared_abi():
@@ -153,3 +153,20 @@ def test_julia_glue_writes_every_timing_key_of_the_reference_operator():
         assert "JCTC.%s" % key in src, key
     for key in ("K_time", "W_time", "V_time", "J_time", "fock_time"):
         assert "JCTiming_key(JCTC.%s, iteration)" % key in src, key
+
+
+def test_group_reduce_plan_partitions_the_fock_matrix():
+    """jcdf_group_reduce_plan (pure host code of the library): the reduce-scatter slices of the N*N elements over the members
+    of a multi-device group — equal chunks of a multiple of 256 elements (what RCCL's in-place reduce-scatter needs), clipped
+    to the matrix, covering it exactly once."""
+    for count in (1, 49, 255, 256, 257, 510 * 510, 1250 * 1250, 1915 * 1915):
+        for n in (1, 2, 3, 4, 7, 8, 16):
+            chunk, off = jc.group_reduce_plan(count, n)
+            assert len(off) == n + 1 and off[0] == 0 and off[-1] == count
+            assert chunk % 256 == 0 and chunk * n >= count and chunk >= -(-count // n)
+            assert all(0 <= b - a <= chunk for a, b in zip(off, off[1:]))
+            assert all(a == min(i * chunk, count) for i, a in enumerate(off))
+            assert chunk - 256 < -(-count // n)                       # no more padding than one granule per member
+    for bad in ((0, 2), (10, 0), (10, 17)):
+        with pytest.raises(jc.JCDFError):
+            jc.group_reduce_plan(*bad)
