@@ -527,6 +527,7 @@ struct CholBuffers {
 hipError_t chol_inverse_device(hipStream_t st, const double *J, int64_t Q, CholBuffers &w, int *info)
 {
 #define CH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+    (void)hipGetLastError();                 // the launches below are checked through it: start from a clean word
     w.n_pad = roundup(Q, 128);
     w.ld = w.n_pad + CH_NB;
     w.nblk = w.n_pad / CH_NB;

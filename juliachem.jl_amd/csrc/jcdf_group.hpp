@@ -177,11 +177,13 @@ int32_t gmember(jcdf_group *g, int i, int32_t rc, const char *what)
 void group_free_buffers(jcdf_group *g)
 {
     for (int i = 0; i < g->n; ++i) {
+        if (!g->m[(size_t)i]) continue;
         (void)hipSetDevice(g->dev[(size_t)i]);
         if ((size_t)i < g->gF.size() && g->gF[(size_t)i]) { (void)hipFree(g->gF[(size_t)i]); g->gF[(size_t)i] = nullptr; }
         if ((size_t)i < g->gT.size() && g->gT[(size_t)i]) { (void)hipFree(g->gT[(size_t)i]); g->gT[(size_t)i] = nullptr; g->gT_doubles[(size_t)i] = 0; }
     }
     if (g->root_red) { (void)hipSetDevice(g->dev[0]); (void)hipFree(g->root_red); g->root_red = nullptr; }
+    (void)hipGetLastError();
 }
 
 void group_release_staging(jcdf_group *g)
@@ -428,11 +430,13 @@ int32_t jcdf_group_destroy(jcdf_group *g)
     group_destroy_comms(g);
     group_free_buffers(g);
     for (int i = 0; i < g->n; ++i) {
+        if (!g->m[(size_t)i]) continue;                  // a member that was never created (jcdf_group_create failed there): its device id may not exist
         (void)hipSetDevice(g->dev[(size_t)i]);
         for (int k = 0; k < jcdf_group::GEV; ++k)
             if ((size_t)(i * jcdf_group::GEV + k) < g->ev.size() && g->E(i, k)) (void)hipEventDestroy(g->E(i, k));
     }
     if (g->ev_order) { (void)hipSetDevice(g->dev[0]); (void)hipEventDestroy(g->ev_order); }
+    (void)hipGetLastError();                             // nothing of a teardown stays behind as the thread's "last error"
     for (auto h : g->m)
         if (h) (void)jcdf_destroy(h);
     delete g;
@@ -540,7 +544,7 @@ int32_t jcdf_group_configure(jcdf_group *g, int64_t N, int64_t Q_total, const in
         JCDF_GHIP(g, hipMemset(g->gF[(size_t)i], 0, bytes));       // the tail beyond N*N takes part in the RCCL reduce-scatter: zeros
     }
     g->configured = true;
-    return JCDF_OK;
+    return group_resolve_transport(g);     // decided (and reported by jcdf_group_transport) before the first build
 }
 
 int32_t jcdf_group_set_metric(jcdf_group *g, const double *J2c)
