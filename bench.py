@@ -192,6 +192,9 @@ def cpu_baseline(N, Q, o, budget_s=12.0):
             "note": "the reference itself (Julia + Libint) cannot run here; this is its algorithm on this box's host cores"}
 
 
+LAST_COLLECTIVES = {}      # per-step ms of the broadcast of C and the all-reduce of F in the most recent run_scf_steps
+
+
 def run_scf_steps(scf, fb, steps, warmup, barrier):
     """W untimed + K timed SCF iterations.  No host call but scf.step() inside the timed loop: the library sums the
     HIP-event times of every build's launches itself (jcdf_kernel_stats_total), the collectives are timed by device events."""
@@ -209,9 +212,11 @@ def run_scf_steps(scf, fb, steps, warmup, barrier):
     recs, nb, fock_sum = fb.h.kernel_stats_total(reset=True)
     nb = max(nb, 1)
     kstats = {r["name"]: dict(seconds=r["seconds"], n=nb, flops=r["flops"], alg_flops=r["alg_flops"], alg_bytes=r["alg_bytes"]) for r in recs}
-    coll_ms = fb.collective_ms() / steps
+    parts = fb.collective_ms(split=True)
     fb.time_collectives = False
-    return elapsed, kstats, fock_sum / nb * 1e3, coll_ms
+    LAST_COLLECTIVES.clear()
+    LAST_COLLECTIVES.update({k: v / steps for k, v in parts.items()})
+    return elapsed, kstats, fock_sum / nb * 1e3, sum(parts.values()) / steps
 
 
 def max_over_ranks(x, world, dev):
@@ -232,7 +237,7 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     import torch
     import juliachem_jl_amd as jc
     from juliachem_jl_amd import synthetic
-    from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
+    from juliachem_jl_amd.engine import DeviceSCF
     N, Q, o = synthetic.CONFIGS["w50"]
     rng = np.random.default_rng(synthetic.SEED + 50)
     pq = (None, None)
@@ -246,20 +251,23 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     shells = synthetic.aux_shells(Q, rng)
     Hs = rng.standard_normal((N, N)); H = 0.5 * (Hs + Hs.T)
     t_setup = time.perf_counter()
-    fb = DeviceFockBuilder(N, Q, o, shells, device=local, pq=pq)
+    fb = make_builder(args, N, Q, o, shells, local, pq)
     fb.set_core_hamiltonian(H)
-    g = torch.Generator(device=dev); g.manual_seed(synthetic.SEED + 1000 + rank)
-    R = len(fb.rows)
-    g1 = torch.randn((R, N), dtype=torch.float64, device=dev, generator=g) * 0.05
-    g2 = torch.randn((R, N), dtype=torch.float64, device=dev, generator=g) * 0.05
-    pd, qd = torch.as_tensor(p, device=dev), torch.as_tensor(q, device=dev)
-    for c0 in range(0, P, 8192):
-        c1 = min(P, c0 + 8192)
-        blk = (g1[:, pd[c0:c1]] * g2[:, qd[c0:c1]] + g1[:, qd[c0:c1]] * g2[:, pd[c0:c1]]).t().contiguous()
-        torch.cuda.synchronize(dev)
-        fb.h.set_B_columns_device(c0, c1, blk.data_ptr())
-    del g1, g2, blk
+    for shard, h, sdev in builder_shards(fb, rank):
+        # shard `shard` of the synthetic tensor, generated on the device that holds it (same numbers whichever process owns it)
+        g = torch.Generator(device=sdev); g.manual_seed(synthetic.SEED + 1000 + shard)
+        R = len(fb.ranges[shard])
+        g1 = torch.randn((R, N), dtype=torch.float64, device=sdev, generator=g) * 0.05
+        g2 = torch.randn((R, N), dtype=torch.float64, device=sdev, generator=g) * 0.05
+        pd, qd = torch.as_tensor(p, device=sdev), torch.as_tensor(q, device=sdev)
+        for c0 in range(0, P, 8192):
+            c1 = min(P, c0 + 8192)
+            blk = (g1[:, pd[c0:c1]] * g2[:, qd[c0:c1]] + g1[:, qd[c0:c1]] * g2[:, pd[c0:c1]]).t().contiguous()
+            torch.cuda.synchronize(sdev)
+            h.set_B_columns_device(c0, c1, blk.data_ptr())
+        del g1, g2, blk
     torch.cuda.empty_cache()
+    R = len(fb.ranges[rank])
     scf = DeviceSCF(fb, H, np.eye(N), 0.0, density_solver=density_solver or args.density_solver)
     torch.cuda.synchronize(dev)
     t_setup = time.perf_counter() - t_setup
@@ -268,10 +276,17 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     elapsed = max_over_ranks(elapsed, world, dev)
     nbytes = fb.h.device_bytes()
     rep = scf.solver_report()
-    fb.close()
     ms = elapsed / steps * 1e3
     Ql = R
-    out = {"value": steps / elapsed, "unit": "SCF iterations/s", "ms_per_step": ms, "steps": steps, "n_gpus_measured": world,
+    n_shards = len(fb.ranges)
+    if args.in_process:
+        # member 0's events cover its shard only: the build of the whole group (fetch of C, longest member, reduce, gather) is
+        # what the step waits for — measured once more on a drained device
+        torch.cuda.synchronize(dev)
+        fb.build_ld(scf.Cop, scf.Fbuf[scf.fi ^ 1])
+        gtm = fb.group_timings()
+        fock_ms = gtm["bcast_ms"] + gtm["build_ms"] + gtm["reduce_ms"] + gtm["gather_ms"]
+    out = {"value": steps / elapsed, "unit": "SCF iterations/s", "ms_per_step": ms, "steps": steps, "n_gpus_measured": n_shards,
            "fock_build_ms": fock_ms, "allreduce_ms": coll_ms, "replicated_ms": ms - fock_ms - coll_ms,
            "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in kstats.items()},
            "kept_pair_fraction": P / float(N * N), "aux_rows_rank0": Ql, "device_GB_rank0": nbytes / 1e9,
@@ -279,8 +294,122 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
            "fock_build_tflops_dense_formula": fock_alg_flops(N, Q, o) / (fock_ms * 1e-3) / 1e12,
            "setup_s": t_setup, "eigensolver": rep, "density_solver": scf.density_solver,
            "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries}
+    if args.in_process:
+        out["group"] = dict(gtm, transport=fb.g.transport())
+    fb.close()
     out["projected_8gpu"] = projected_8gpu(out, 8.0 * N * N)
     return out
+
+
+def measure_host_boundary(jc, N, Q, o, J2c, H, T_dev, C_occ, device, builds=8):
+    """One Fock build through the host entry points a JuliaChem caller binds (julia/JCDFHip.jl): `jcdf_fock_build` on one
+    handle and `jcdf_group_fock_build` on a one-device group with either reduce transport — C_occ from host memory, F into
+    host memory, so H2D / D2H over PCIe and the call's synchronisation are inside the time.  Same tensor as the timed loop."""
+    import torch
+    out = {"note": "host C_occ -> host F through the C ABI, PCIe inclusive; ms per build, median of %d" % builds}
+    T_dev = T_dev.contiguous()
+    torch.cuda.synchronize()
+
+    def run(fn):
+        fn()
+        ts = []
+        for _ in range(builds):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+    h = jc.JCDFHandle(device)
+    h.configure(N, Q, 0, Q, o)
+    h.set_metric(np.tril(J2c))
+    h.push_three_center_device(0, Q, T_dev.data_ptr())
+    h.set_core_hamiltonian(H)
+    F_ref, t = h.fock_build(C_occ)
+    out["jcdf_fock_build_ms"] = run(lambda: h.fock_build(C_occ))
+    out["device_fock_ms"] = t.fock_time * 1e3
+    out["copy_ms"] = t.copy_time * 1e3
+    h.close()
+    for transport in ("peer", "rccl"):
+        try:
+            g = jc.JCDFGroup([device])
+            g.set_transport(transport)
+            g.configure(N, Q, [0, Q], o)
+            g.set_metric(np.tril(J2c))
+            g.push_three_center_device(0, Q, T_dev.data_ptr())
+            g.set_core_hamiltonian(H)
+            F, _, gt = g.fock_build(C_occ)
+            out["group_1dev_%s" % transport] = {"ms": run(lambda: g.fock_build(C_occ)), "transport": g.transport(),
+                                                "bit_equal_to_handle": bool(np.array_equal(F, F_ref)),
+                                                "bcast_ms": gt.bcast_time * 1e3, "reduce_ms": gt.reduce_time * 1e3, "d2h_ms": gt.d2h_time * 1e3}
+            g.close()
+        except Exception as e:                               # informational object: never fail the bench line for it
+            out["group_1dev_%s" % transport] = {"error": repr(e)}
+    return out
+
+
+def distributed_record(world, rank, dev, fb, fock_ms, coll_parts, b_exchange):
+    """What makes a multi-GPU line checkable from the line alone (every rank takes part, rank 0 keeps the result): the
+    collective backend and its version, the number of ranks an all-reduce of ones actually sees, every rank's aux rows,
+    device and Fock-build time (all-gathered), the broadcast of C and the all-reduce of F timed separately, and the
+    doubles each rank sent / received in the one-time B exchange."""
+    import torch
+    rec = {"world_size": world, "collective_backend": None, "rccl_version": None, "ranks_seen": 1,
+           "aux_rows": [len(fb.rows)] if world == 1 else None, "fock_build_ms": [fock_ms], "device_index": [dev.index],
+           "bcast_ms": coll_parts.get("bcast", 0.0), "allreduce_ms": coll_parts.get("allreduce", 0.0),
+           "b_exchange_doubles_sent": [int(b_exchange.get("sent", 0))], "b_exchange_doubles_received": [int(b_exchange.get("received", 0))]}
+    try:
+        v = torch.cuda.nccl.version()
+        rec["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:
+        rec["rccl_version"] = "unavailable: %r" % (e,)
+    if world > 1:
+        dist = torch.distributed
+        backend = dist.get_backend()
+        cdev = dev if backend == "nccl" else "cpu"
+        rec["collective_backend"] = backend
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(ones)
+        rec["ranks_seen"] = int(round(float(ones.item())))
+        mine = torch.tensor([float(len(fb.rows)), float(fock_ms), float(dev.index), float(b_exchange.get("sent", 0)),
+                             float(b_exchange.get("received", 0)), float(fb.rows.start)], dtype=torch.float64, device=cdev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        rows = [[float(x) for x in t.cpu().tolist()] for t in allv]
+        rec["aux_rows"] = [int(r[0]) for r in rows]
+        rec["fock_build_ms"] = [r[1] for r in rows]
+        rec["device_index"] = [int(r[2]) for r in rows]
+        rec["b_exchange_doubles_sent"] = [int(r[3]) for r in rows]
+        rec["b_exchange_doubles_received"] = [int(r[4]) for r in rows]
+        rec["aux_row_start"] = [int(r[5]) for r in rows]
+        rec["consistent"] = bool(rec["ranks_seen"] == world and sum(rec["aux_rows"]) == fb.Q_total and dist.get_world_size() == world)
+    else:
+        rec["consistent"] = True
+    return rec
+
+
+def make_builder(args, N, Q, o, shells, local, pq=(None, None)):
+    """one rank per GPU (torch.distributed, default) or ONE process over all --gpus devices (--in-process: jcdf_group_*)"""
+    from juliachem_jl_amd.engine import DeviceFockBuilder, GroupFockBuilder
+    if not args.in_process:
+        return DeviceFockBuilder(N, Q, o, shells, device=local, pq=pq)
+    import torch
+    ndev = torch.cuda.device_count()
+    if os.environ.get("JCDF_BENCH_SHARE_DEVICE") == "1":         # rehearsal on a one-GPU box: the members share the device
+        devices = [i % max(1, ndev) for i in range(args.gpus)]
+    elif args.gpus > ndev:
+        sys.stderr.write("bench.py --in-process: %d devices asked for, the node shows %d (JCDF_BENCH_SHARE_DEVICE=1 shares one GPU)\n"
+                         % (args.gpus, ndev))
+        raise SystemExit(2)
+    else:
+        devices = list(range(args.gpus))
+    return GroupFockBuilder(N, Q, o, shells, devices, pq=pq, transport=None if args.transport == "auto" else args.transport)
+
+
+def builder_shards(fb, rank):
+    """(shard index, handle, torch device) of every aux shard this process holds"""
+    import torch
+    if hasattr(fb, "g"):
+        return [(i, m, torch.device("cuda", d)) for i, (m, d) in enumerate(zip(fb.g.members, fb.devices))]
+    return [(rank, fb.h, fb.device)]
 
 
 def parse_args(argv=None):
@@ -292,6 +421,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-w50", action="store_true", help="skip the scaling_w50 object")
     ap.add_argument("--no-real", action="store_true", help="skip the real_molecule object (profiling runs)")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the host_boundary object (host C in, host F out through the C ABI)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process drives all --gpus devices through the C ABI's multi-device group (jcdf_group_*: C fetched "
+                         "device-to-device, F reduced on the devices, the SCF loop on device 0 only) instead of one rank per GPU over "
+                         "torch.distributed; same workload, same metric — the two transports of an 8-GPU node side by side")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"], help="--in-process: the group's reduce transport")
     ap.add_argument("--density-solver", default="eigh", choices=["eigh", "sp2"],
                     help="eigh: the reference's eigensolve per iteration (default, what `value` is quoted on); sp2: spectral projection")
     return ap.parse_args(argv)
@@ -349,13 +484,18 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ:
+    if args.in_process:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.stderr.write("bench.py --in-process is ONE process over all devices: start it without a launcher\n")
+            raise SystemExit(2)
+        world = 1                                              # torch sees a single-rank job; the devices are the group's members
+    elif "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             raise SystemExit(launch_ranks(args, argv))
         world = 1
     else:
         world = int(os.environ["WORLD_SIZE"])
-    if world != args.gpus:
+    if world != args.gpus and not args.in_process:
         # a record that says n_gpus = 1 for a run asked to use 8 (or the reverse) must never exist
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or drop the launcher: "
                          "bench.py starts its own ranks)\n" % (args.gpus, world, args.gpus))
@@ -364,7 +504,7 @@ def main(argv=None):
     import torch
     import juliachem_jl_amd as jc
     from juliachem_jl_amd import synthetic
-    from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
+    from juliachem_jl_amd.engine import DeviceSCF
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -401,17 +541,26 @@ def main(argv=None):
     shells = synthetic.aux_shells(Q, rng)
 
     t_setup = time.perf_counter()
-    fb = DeviceFockBuilder(N, Q, o, shells, device=local)
+    fb = make_builder(args, N, Q, o, shells, local)
+    n_shards = len(fb.ranges)
+    shard_rows = [len(r) for r in fb.ranges]
     fb.set_metric(J2c)
     fb.set_core_hamiltonian(H)
-    # this rank's three-centre block, generated on the device: [p][q][a] contiguous == (rows, N*N) column-major
-    g = torch.Generator(device=dev); g.manual_seed(synthetic.SEED + 17 * rank)
-    R = len(fb.rows)
-    A = torch.randn((N, N, R), dtype=torch.float64, device=dev, generator=g) * 0.1
-    T_own = (0.5 * (A + A.transpose(0, 1))).contiguous().reshape(-1)
-    del A
-    fb.exchange_three_center(T_own)
-    del T_own
+
+    def shard_block(i):
+        # aux shard i's three-centre block, generated on this process's device: [p][q][a] contiguous == (rows, N*N) column-major
+        # (seeded by the shard, so one rank per GPU and one process over all GPUs contract the same tensor)
+        g = torch.Generator(device=dev); g.manual_seed(synthetic.SEED + 17 * i)
+        A = torch.randn((N, N, shard_rows[i]), dtype=torch.float64, device=dev, generator=g) * 0.1
+        return (0.5 * (A + A.transpose(0, 1))).contiguous().reshape(-1)
+    if args.in_process:
+        b_exchange = {"sent": 0, "received": 0, "recv_buffer": 0}
+        for i, r in enumerate(fb.ranges):                      # every shard is in this process: pushed block by block
+            fb.push_three_center_device(r.start, r.stop, shard_block(i))
+    else:
+        T_own = shard_block(rank)
+        b_exchange = fb.exchange_three_center(T_own)
+        del T_own
     torch.cuda.empty_cache()
     scf = DeviceSCF(fb, H, S, 0.0, density_solver=args.density_solver)
     torch.cuda.synchronize(dev)
@@ -423,6 +572,18 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
 
     elapsed, kstats, fock_ms, coll_ms = run_scf_steps(scf, fb, args.steps, args.warmup, barrier)
+    coll_parts = dict(LAST_COLLECTIVES)
+    member0_fock_ms = fock_ms
+    group_obj = None
+    if args.in_process:
+        # member 0's events cover its shard; the step waits for the whole group build: fetch of C, longest member, reduce, gather
+        torch.cuda.synchronize(dev)
+        fb.build_ld(scf.Cop, scf.Fbuf[scf.fi ^ 1])
+        gtm = fb.group_timings()
+        fock_ms = gtm["bcast_ms"] + gtm["build_ms"] + gtm["reduce_ms"] + gtm["gather_ms"]
+        group_obj = dict(gtm, transport=fb.g.transport(), devices=fb.devices, member0_fock_ms_timed_loop=member0_fock_ms,
+                         aux_rows=[len(r) for r in fb.ranges])
+    dist_obj = distributed_record(world, rank, dev, fb, fock_ms, coll_parts, b_exchange)
     # outside the timed region: stand-alone duration of the HBM-streaming J pass (in the timed steps it runs beside the
     # MFMA-bound K pass on a side stream and takes longer while it shares the device)
     fb.h.set_overlap(False)
@@ -460,15 +621,25 @@ def main(argv=None):
                        "library's own cores; same energies; not the default, not `value`"}
     elapsed = max_over_ranks(elapsed, world, dev)
     solver_report = scf.solver_report()
+    rows0 = len(fb.ranges[0])
+    onehop_max_n = int(jc._lib.load().jcdf_sytrd_max_n(1))
+    Co_host = scf.Co_t.t().contiguous().cpu().numpy()           # (N, n_occ): what a host caller hands over
     fb.close()
     del scf, fb
     torch.cuda.empty_cache()
+    # the C ABI as the reference's Julia caller uses it: host C_occ in, host F out (PCIe inclusive; never `value`)
+    host_boundary = None
+    if n_shards == 1 and world == 1 and not args.no_host_boundary:
+        host_boundary = measure_host_boundary(jc, N, Q, o, J2c, H, shard_block(0), np.asfortranarray(Co_host), local)
+        torch.cuda.empty_cache()
 
     # the strong-scaling workload of north_star, same ranks, same run (never `value`)
     w50 = None
     if not args.no_w50:
         w50 = {"workload": "(H2O)50 / cc-pVDZ + cc-pVDZ-RIFIT shaped DF-RHF SCF iteration: N=1250 AO, Q=4800 aux, n_occ=250, aux index "
-                           "sharded over %d GPU(s), C broadcast + F all-reduce over RCCL per iteration" % world,
+                           "sharded over %d GPU(s), %s per iteration"
+                           % (n_shards, "one process (jcdf_group): C fetched device-to-device, F reduced on the devices" if args.in_process
+                              else "C broadcast + F all-reduce over RCCL"),
                "screened_13pct": measure_w50(args, world, rank, local, dev, barrier, 0.13),
                "dense_map": measure_w50(args, world, rank, local, dev, barrier, None),
                # the same screened problem with the optional spectral-projection density solver (no eigensolve per
@@ -484,16 +655,16 @@ def main(argv=None):
         w_avg = w["seconds"] / w["n"]
         w_alg = w["alg_flops"]                  # algorithmic flops of ONE launch (this rank's aux shard)
         achieved = w_alg / w_avg / 1e12
-        traffic, traffic_src = pmc_traffic("k_exchange_W", (N, Q, o), world)
-        step_rec, step_why = checked_record(STEP_RECORD, (N, Q, o)) if world == 1 else (None, "single-GPU record")
-        k_pmc, k_why = pmc_kernel("k_exchange_K64", (N, Q, o), world)
-        w_pmc, _ = pmc_kernel("k_exchange_W", (N, Q, o), world)
+        traffic, traffic_src = pmc_traffic("k_exchange_W", (N, Q, o), n_shards)
+        step_rec, step_why = checked_record(STEP_RECORD, (N, Q, o)) if n_shards == 1 else (None, "single-GPU record")
+        k_pmc, k_why = pmc_kernel("k_exchange_K64", (N, Q, o), n_shards)
+        w_pmc, _ = pmc_kernel("k_exchange_W", (N, Q, o), n_shards)
         kk = kstats["k_exchange_K"]
         k_avg = kk["seconds"] / kk["n"]
-        k_useful = Q * o * N * (N + 1.0) / world                                  # this rank's shard
+        k_useful = rows0 * o * N * (N + 1.0)                                      # this rank's (member 0's) aux shard
         longest = None
         if sytrd_ms is not None:
-            longest = {"kernel": ("k_sytrd_onehop" if N <= 1000 else "k_sytrd_lower") + " (columns 0 .. N-129) + k_sytd2_tail (last 128, one workgroup) + k_q_tail_reflect",
+            longest = {"kernel": ("k_sytrd_onehop" if N <= onehop_max_n else "k_sytrd_lower") + " (columns 0 .. N-129) + k_sytd2_tail (last 128, one workgroup) + k_q_tail_reflect",
                        "role": "replicated eigensolve, tridiagonalisation + Q (caller side, SCF.jl:1083)",
                        "ms": sytrd_ms, "us_per_column": sytrd_ms * 1e3 / N, "share_of_ms_per_step": sytrd_ms / ms,
                        "bound": "latency: one chip-wide hand-off per column (4.6-7 us), 1.7 us per column inside the one-workgroup tail; not on a flop or byte roofline",
@@ -501,12 +672,20 @@ def main(argv=None):
                        "stedc_ms": stedc_ms, "measured": "device events around the launch over 5 iterations after the timed loop"}
         out = {
             "metric": "SCF iterations/sec (DF-RHF, C20H42/cc-pVDZ shape); Fock-build TFLOP/s in fock_build_useful_tflops / fock_build_tflops_dense_formula",
-            "value": args.steps / elapsed, "unit": "SCF iterations/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps / elapsed, "unit": "SCF iterations/s", "n_gpus": n_shards, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s/cc-pVDZ + cc-pVDZ-RIFIT shaped DF-RHF SCF iteration: N=%d AO, Q=%d aux, n_occ=%d, "
-                                   "dense pq map, aux index sharded over %d GPU(s), F all-reduce over RCCL"
-                                   % (args.config, N, Q, o, world)},
+                                   "dense pq map, aux index sharded over %d GPU(s), %s"
+                                   % (args.config, N, Q, o, n_shards,
+                                      "ONE process, jcdf_group: C fetched device-to-device, F reduced on the devices, SCF loop on device 0"
+                                      if args.in_process else "one rank per GPU, C broadcast + F all-reduce over RCCL"),
+                       "transport": "in-process group" if args.in_process else "torch.distributed"},
+            # what an N-GPU record can be checked with: backend, RCCL version, ranks an all-reduce of ones saw, every rank's
+            # aux rows / device / Fock-build time, the broadcast of C and the all-reduce of F timed separately, B-exchange traffic
+            "distributed": dist_obj,
+            "in_process_group": group_obj,
+            "host_boundary": host_boundary,
             "density_solver": {"name": scf_name(args), "trail_note": "the timed steps sit on the converged fixed point of the synthetic problem "
                                "(all work executed; DIIS takes its singular branch); real-molecule iterations: real_molecule",
                                "eigensolver": solver_report},
@@ -523,9 +702,9 @@ def main(argv=None):
                                    if step_rec else step_why,
             # useful = what must be executed (K symmetric, W on the kept pairs); dense_formula = SURVEY 8d's F_alg (K counted twice over)
             "fock_build_useful_tflops": f_use / (fock_ms * 1e-3) / 1e12,
-            "fock_build_useful_pct_fp64_mfma_peak": 100.0 * f_use / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "fock_build_useful_pct_fp64_mfma_peak": 100.0 * f_use / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * n_shards),
             "fock_build_tflops_dense_formula": f_alg / (fock_ms * 1e-3) / 1e12,          # whole job (all shards)
-            "fock_build_pct_fp64_mfma_peak_dense_formula": 100.0 * f_alg / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "fock_build_pct_fp64_mfma_peak_dense_formula": 100.0 * f_alg / (fock_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * n_shards),
             "setup_s": t_setup,
             "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in kstats.items()},
             "kernels_executed_tflops": {k: v["flops"] / (v["seconds"] / v["n"]) / 1e12 for k, v in kstats.items() if v["flops"] > 0},
@@ -551,9 +730,9 @@ def main(argv=None):
             "longest_kernel": longest,
             "scaling_w50": w50,
         }
-        if world == 1 and not args.no_real:
+        if n_shards == 1 and not args.no_real:
             out["real_molecule"] = real_molecule()
-        if world == 1 and not args.no_cpu_baseline:
+        if n_shards == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, Q, o)
             out["speedup_vs_cpu_iteration"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_fock_build"] = out["cpu_baseline"]["fock_build_s"] / (fock_ms * 1e-3)

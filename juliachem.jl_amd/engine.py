@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .df import JCDFHandle, lapack_potrf_trtri
+from .df import JCDFGroup, JCDFHandle, lapack_potrf_trtri
 from .eigh import DeviceEigh
 
 
@@ -167,7 +167,7 @@ class DeviceFockBuilder:
         self.h.configure(N, Q_total, self.rows.start, self.rows.stop, n_occ, pq[0], pq[1])
         self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
         self.time_collectives = False      # bench: device events around the broadcast of C and the all-reduce of F
-        self.collective_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.collective_events: list = []
 
     # ---- setup -----------------------------------------------------------------
     def set_metric(self, J2c: np.ndarray) -> None:
@@ -205,11 +205,11 @@ class DeviceFockBuilder:
         if self.world > 1:
             ev = self._collective_begin()
             _broadcast(self.dist, C_occ_dev, 0)
-            self._collective_end(ev)
+            self._collective_end(ev, "bcast")
         self.h.fock_build_device(C_occ_dev.data_ptr(), self.F.data_ptr())
         ev = self._collective_begin()
         out = allreduce_fock(self.F, self.world, self.dist)    # RCCL ncclAllReduce(N^2 fp64) over xGMI
-        self._collective_end(ev)
+        self._collective_end(ev, "allreduce")
         return out
 
     def build_ld(self, C_pad: torch.Tensor, F_pad: torch.Tensor) -> torch.Tensor:
@@ -219,11 +219,11 @@ class DeviceFockBuilder:
         if self.world > 1:
             ev = self._collective_begin()
             _broadcast(self.dist, C_pad, 0)
-            self._collective_end(ev)
+            self._collective_end(ev, "bcast")
         self.h.fock_build_device_ld(C_pad.data_ptr(), C_pad.stride(0), F_pad.data_ptr(), F_pad.stride(0))
         ev = self._collective_begin()
         out = allreduce_fock(F_pad, self.world, self.dist)
-        self._collective_end(ev)
+        self._collective_end(ev, "allreduce")
         return out
 
     def _collective_begin(self):
@@ -233,20 +233,102 @@ class DeviceFockBuilder:
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
-    def _collective_end(self, ev) -> None:
+    def _collective_end(self, ev, tag: str = "allreduce") -> None:
         if ev is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
-            self.collective_events.append((ev, e1))
+            self.collective_events.append((tag, ev, e1))
 
-    def collective_ms(self) -> float:
-        """sum of the recorded collective durations (ms); clears the record.  Call after a device synchronise."""
-        tot = sum(a.elapsed_time(b) for a, b in self.collective_events)
+    def collective_ms(self, split: bool = False):
+        """sum of the recorded collective durations (ms); clears the record.  Call after a device synchronise.
+        split = True: {"bcast": ms, "allreduce": ms} (the broadcast of C and the all-reduce of F separately)."""
+        parts = {"bcast": 0.0, "allreduce": 0.0}
+        for tag, a, b in self.collective_events:
+            parts[tag] = parts.get(tag, 0.0) + float(a.elapsed_time(b))
         self.collective_events = []
-        return float(tot)
+        return parts if split else float(sum(parts.values()))
 
     def close(self) -> None:
         self.h.close()
+
+
+class GroupFockBuilder:
+    """The same interface as `DeviceFockBuilder` for ONE process that drives several GPUs (include/jcdf.h, jcdf_group_*):
+    member i of the group holds aux shard i on devices[i]; the SCF loop (DIIS, eigensolve, density: `DeviceSCF`) lives on
+    devices[0] only — nothing is replicated — and every Fock build is sharded over all devices: C_occ is fetched by the
+    other devices device-to-device, the partial Fock matrices are summed on the devices (RCCL reduce / peer-mapped slice
+    sums over xGMI) and gathered where the caller's F lives (`jcdf_group_fock_build_device_ld`).  From torch's point of
+    view this is a single-rank job: rank 0, world 1, no process group."""
+
+    def __init__(self, N: int, Q_total: int, n_occ: int, aux_shell_nbas: Sequence[int], devices: Sequence[int],
+                 pq: Tuple[Optional[np.ndarray], Optional[np.ndarray]] = (None, None), exchange_screen_blocks: int = 0,
+                 tuning: Optional[dict] = None, transport: Optional[str] = None):
+        self.rank, self.world, self.dist = 0, 1, None
+        self.devices = [int(d) for d in devices]
+        self.device = torch.device("cuda", self.devices[0])
+        torch.cuda.set_device(self.device)
+        self.N, self.Q_total, self.n_occ = N, Q_total, n_occ
+        self.ranges = shard_ranges(aux_shell_nbas, len(self.devices))
+        if any(len(r) == 0 for r in self.ranges):
+            raise ValueError("empty auxiliary shard: more devices than auxiliary shells")
+        self.rows = range(0, Q_total)                      # this process holds every shard
+        self.g = JCDFGroup(self.devices)
+        if transport:
+            self.g.set_transport(transport)
+        self.g.set_exchange_screening(exchange_screen_blocks)
+        for key, value in (tuning or {}).items():
+            for m in self.g.members:
+                m.set_tuning(key, value)
+        self.g.configure(N, Q_total, [r.start for r in self.ranges] + [Q_total], n_occ, pq[0], pq[1])
+        self.h = self.g.members[0]                          # kernel statistics / overlap switch of member 0 (its shard)
+        # member 0 works on torch's current stream, like DeviceFockBuilder's handle: no event hop between the SCF kernels and
+        # its shard of the build; the other members keep their own streams (ordered by the group's events)
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.F = torch.zeros((N, N), dtype=torch.float64, device=self.device)
+        self.time_collectives = False
+        self.collective_events: list = []
+
+    def set_metric(self, J2c: np.ndarray) -> None:
+        self.g.set_metric(J2c)
+
+    def set_core_hamiltonian(self, H: np.ndarray) -> None:
+        self.g.set_core_hamiltonian(H)
+
+    def push_three_center_device(self, s0: int, s1: int, T_dev: torch.Tensor) -> None:
+        """T_dev: device tensor (any device of this process) holding the (s1-s0, P) column-major block"""
+        torch.cuda.synchronize(T_dev.device)
+        self.g.push_three_center_device(s0, s1, T_dev.data_ptr())
+
+    def exchange_three_center(self, T_own: torch.Tensor, block: Optional[int] = None) -> dict:
+        """every shard's block is already in this process: pushed shard by shard (the library uploads / fetches each block
+        once and hands it to the members behind it device-to-device) — no inter-process traffic"""
+        P = T_own.numel() // self.Q_total
+        Tm = T_own.view(P, self.Q_total)                    # (rows, P) column-major == [c][row]
+        for r in self.ranges:
+            self.push_three_center_device(r.start, r.stop, Tm[:, r.start:r.stop].contiguous().view(-1))
+        return {"sent": 0, "received": 0, "recv_buffer": 0}
+
+    def build(self, C_occ_dev: torch.Tensor) -> torch.Tensor:
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.g.fock_build_device_ld(C_occ_dev.data_ptr(), C_occ_dev.stride(0), self.F.data_ptr(), self.N, st)
+        return self.F
+
+    def build_ld(self, C_pad: torch.Tensor, F_pad: torch.Tensor) -> torch.Tensor:
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.g.fock_build_device_ld(C_pad.data_ptr(), C_pad.stride(0), F_pad.data_ptr(), F_pad.stride(0), st)
+        return F_pad
+
+    def collective_ms(self, split: bool = False):
+        return {"bcast": 0.0, "allreduce": 0.0} if split else 0.0
+
+    def group_timings(self) -> dict:
+        """device-side times of the LAST build (after a synchronise): C fetch, longest member build, reduce, gather"""
+        t, gt = self.g.synchronize()
+        return {"bcast_ms": gt.bcast_time * 1e3, "build_ms": gt.build_time * 1e3, "reduce_ms": gt.reduce_time * 1e3,
+                "gather_ms": gt.d2h_time * 1e3, "member_fock_ms": [x.fock_time * 1e3 for x in t]}
+
+    def close(self) -> None:
+        self.g.close()
 
 
 class DeviceSCF:

@@ -66,6 +66,16 @@ def test_bench_prints_the_contract_line():
     # the optional spectral-projection density solver is reported beside, on the same problem, with the same energy
     assert d["density_solver"]["name"] == "eigh"
     assert d["alt"]["density_solver"] == "sp2" and d["alt"]["value"] > 50.0 and abs(d["alt"]["energy_minus_eigh"]) < 1e-6
+    # the self-verification record of a (here: one-rank) run, and the host boundary of the C ABI (PCIe inclusive)
+    ds = d["distributed"]
+    assert ds["world_size"] == 1 and ds["ranks_seen"] == 1 and ds["aux_rows"] == [1950] and ds["consistent"] is True
+    assert ds["allreduce_ms"] == 0.0 and ds["bcast_ms"] == 0.0 and ds["rccl_version"]
+    assert d["in_process_group"] is None and d["config"]["transport"] == "torch.distributed"
+    hb = d["host_boundary"]
+    assert hb["jcdf_fock_build_ms"] > hb["device_fock_ms"] > 1.0
+    for tr in ("peer", "rccl"):
+        assert hb["group_1dev_" + tr]["bit_equal_to_handle"] is True, hb
+        assert hb["group_1dev_" + tr]["transport"].startswith(tr)
 
 
 @pytest.mark.gpu
@@ -87,6 +97,42 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert w50 is not None and w50["screened_13pct"]["allreduce_ms"] > 0.0
     assert w50["screened_13pct"]["aux_rows_rank0"] < 4800          # rank 0 holds a shard of the aux index, not all of it
     assert "cpu_baseline" not in d and "real_molecule" not in d
+    # what makes an N-GPU record checkable from the line alone
+    ds = d["distributed"]
+    assert ds["world_size"] == 2 and ds["collective_backend"] == "gloo" and ds["ranks_seen"] == 2 and ds["consistent"] is True
+    assert len(ds["aux_rows"]) == 2 and sum(ds["aux_rows"]) == 1950 and ds["aux_row_start"] == [0, ds["aux_rows"][0]]
+    assert len(ds["fock_build_ms"]) == 2 and all(x > 0 for x in ds["fock_build_ms"]) and len(ds["device_index"]) == 2
+    assert ds["allreduce_ms"] > 0.0 and ds["bcast_ms"] > 0.0 and abs(ds["allreduce_ms"] + ds["bcast_ms"] - d["allreduce_ms"]) < 1e-9
+    # the one-time B exchange is the lower triangle: rank 0 sends its block to rank 1 and receives nothing
+    P = 510 * 510
+    assert ds["b_exchange_doubles_sent"] == [ds["aux_rows"][0] * P, 0] and ds["b_exchange_doubles_received"] == [0, ds["aux_rows"][0] * P]
+    assert ds["rccl_version"] and d["host_boundary"] is None and d["in_process_group"] is None
+
+
+@pytest.mark.gpu
+def test_bench_in_process_group_rehearsal():
+    """`bench.py --gpus 2 --in-process`: ONE process, the devices behind the C ABI's multi-device group (C fetched device-to-device,
+    F reduced on the devices, the SCF loop on device 0).  On the one-GPU box the two members share the card
+    (JCDF_BENCH_SHARE_DEVICE=1, "peer" transport): timings mean nothing here, the record's shape and the energy do."""
+    env = dict(os.environ, JCDF_BENCH_SHARE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--in-process", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-real"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "in-process group" and d["allreduce_ms"] == 0.0
+    g = d["in_process_group"]
+    assert g["transport"].startswith("peer") and g["devices"] == [0, 0] and sum(g["aux_rows"]) == 1950
+    assert len(g["member_fock_ms"]) == 2 and all(x > 0 for x in g["member_fock_ms"]) and g["reduce_ms"] > 0 and g["gather_ms"] > 0
+    assert abs(d["fock_build_ms"] - (g["bcast_ms"] + g["build_ms"] + g["reduce_ms"] + g["gather_ms"])) < 1e-9
+    assert d["distributed"]["world_size"] == 1 and d["host_boundary"] is None
+    w50 = d["scaling_w50"]["screened_13pct"]
+    assert w50["n_gpus_measured"] == 2 and w50["group"]["transport"].startswith("peer") and w50["aux_rows_rank0"] < 4800
+    # the same SCF as the one-rank-per-GPU path: the sp2 run reproduces the eigensolver's energy through the group as well
+    assert abs(d["alt"]["energy_minus_eigh"]) < 1e-6
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
