@@ -187,3 +187,55 @@ def test_operator_with_num_devices_2_goes_through_the_group(monkeypatch):
     assert tm.non_timing_data["contraction_algorithm"] == "dense hip"       # adaptive rule: N < 800 on one rank
     assert "GPU_2_K_time-2" in tm.timings and tm.timings["fock_gpu_cpu_copy_reduce_time-2"] > 0
     scf_data.gpu_data.close()
+
+
+def _operator_rank(rank, world, port, out, num_devices):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", JCDF_ALLOW_DEVICE_WRAP="1")
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, Q, o = 60, 97, 7
+        s = synthetic.make(N, Q, o, seed=12, kept_fraction=0.6)
+        bs = jc.CalculationBasisSets(jc.basis_from_shell_sizes([N], nels=2 * o), jc.basis_from_shell_sizes(s.aux_shell_nbas))
+        eng = jc.TensorIntegralEngine(s.J2c, s.T, mask=s.mask)
+        opts = jc.create_scf_options({"scf_type": "df", "contraction_mode": "GPU", "num_devices": num_devices})
+        scf_data = jc.SCFData(jc.get_default_gpu_data_hip())
+        tm = jc.create_jctiming()
+        F = jc.df_rhf_fock_build(scf_data, eng, None, bs, s.C, 1, opts, s.H, tm)
+        sd = orc.get_screening_metadata(s.mask)
+        Bp = orc.pack_three_center(orc.calculate_B(s.J2c, s.T), sd)
+        ref = s.H + orc.df_rhf_fock_build_screened(Bp, s.C[:, :o], sd)
+        rows = [len(r) for r in scf_data.gpu_data.device_Q_indices]
+        out.put((rank, float(_rel(F, ref)), tm.non_timing_data["contraction_algorithm"], int(tm.non_timing_data["B_exchange_doubles_sent"]),
+                 int(tm.non_timing_data["B_exchange_doubles_received"]), rows, int(sd.screened_indices_count),
+                 tm.non_timing_data.get("GPU_reduce_transport", "")))
+        scf_data.gpu_data.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_devices", [1, 2])
+def test_reference_shaped_operator_on_two_ranks(num_devices):
+    """df_rhf_fock_build on two processes (gloo rehearsal on the one GPU), one or two devices per rank (global device id =
+    rank * num_devices + dev, GPUDF.jl:1026-1056; two devices per rank = one jcdf_group per rank): multi-rank runs take the
+    screened layout (DensityFitting.jl:78-90); the one-time B formation inside calculate_B_GPU is the point-to-point lower
+    triangle (rank 0 sends its block to rank 1 and receives nothing), F is all-reduced across the ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_operator_rank, args=(r, 2, port, out, num_devices)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(2))
+    for rank, err, algo, sent, recv, rows, P, transport in got:
+        assert err < RTOL and algo == "screened hip" and len(rows) == 2 * num_devices and sum(rows) == 97
+        own0 = sum(rows[:num_devices])
+        assert (sent, recv) == ((own0 * P, 0) if rank == 0 else (0, own0 * P))
+        assert transport.startswith("peer") == (num_devices == 2)
