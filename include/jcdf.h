@@ -229,10 +229,22 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
  * reflectors travel between workgroups (the last 128 reflectors by one row-parallel launch), so the
  * eigenvectors of A are ONE GEMM Q*Z away (instead of LAPACK's dormtr back-transformation).  d_Q may be NULL (== jcdf_sytrd_device).
  * jcdf_sytrd_max_n(with_q): largest n whose working set fits the LDS of the device (JCDF_ERR_INVALID above):
- * 1536 with Q (the one-exchange kernel: rows of Q in registers), ~2040 without. */
+ * 1536 with Q (the one-exchange kernel: rows of Q in registers), ~2040 without (there the first n - 1536 columns go through
+ * the two-exchange kernel and the trailing 1536 x 1536 block through the one-exchange kernel; the eigenvectors then take
+ * jcdf_ormtr_device instead of the GEMM with Q). */
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* Back-transformation of the same eigensolve for the sizes above jcdf_sytrd_max_n(1), where Q is not accumulated in the
+ * tridiagonalisation (LAPACK dormtr('L','L','N') semantics, the third stage of dsyevd behind SCF.jl:1083): C <- Q C with
+ * Q = H_0 H_1 ... from the reflectors and d_TAU that jcdf_sytrd_device left in d_A, by blocked compact-WY on the library's
+ * fp64 MFMA cores (csrc/jcdf_wy.hpp; no vendor kernel).  d_Ct holds C TRANSPOSED — row j = column j of C, contiguous, what
+ * jcdf_stedc_device writes with ldz = ldc — zero padded to roundup(n, 32) rows and columns (ldc >= that, even); it is
+ * updated in place.  d_Out (optional): the result once more as a row-major matrix [component][vector] with leading dimension
+ * ldo >= roundup(n, 32), zero padded (the operand shape of jcdf_gemm_tn_device).  d_work: jcdf_ormtr_workspace_bytes(n). */
+int64_t jcdf_ormtr_workspace_bytes(int64_t n);
+int32_t jcdf_ormtr_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU, double *d_Ct, int64_t ldc,
+                          double *d_Out, int64_t ldo, void *d_work, int64_t work_bytes);
 /* The Pulay (DIIS) step of the SCF wrapper on the device, so that the iteration needs no round trip to the host
  * between the Fock build and the eigensolve (reference: DIIS, EnergyHelpers.jl:234-258, called at SCF.jl:472-501):
  * d_Bmat nd x nd ring buffer of error-vector dot products (row and column `head` are first overwritten with
@@ -245,7 +257,9 @@ int32_t jcdf_diis_device(void *stream, int32_t nd, int32_t head, int32_t n, int3
  * matrix (d_D diagonal, d_E sub-diagonal, both device, length n and n-1) by divide & conquer
  * (LAPACK dstedc 'I' semantics; csrc/jcdf_dc.hpp).  On return (stream-ordered) d_D holds the eigenvalues
  * ascending and d_Z (n x n column-major, leading dimension ldz) the eigenvectors in its columns; d_E is
- * unchanged.  d_work: jcdf_stedc_workspace_bytes(n) bytes of device memory. */
+ * unchanged.  d_work: jcdf_stedc_workspace_bytes(n) bytes of device memory (-1: n is too large for this solver, ~2700 rows:
+ * known before anything is enqueued); its int at byte offset 0 is non-zero afterwards if a leaf's QL iteration did not
+ * converge (non-finite input does this): the decomposition must then not be used. */
 int64_t jcdf_stedc_workspace_bytes(int64_t n);
 int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, double *d_Z, int64_t ldz,
                           void *d_work, int64_t work_bytes);

@@ -12,6 +12,7 @@
 #include "jcdf_sp2.hpp"
 #include "jcdf_scf.hpp"
 #include "jcdf_blas.hpp"
+#include "jcdf_wy.hpp"
 #ifdef JCDF_DIAGNOSTIC            // tools/build_diag.sh: ablations, experiment kernels and the variant knobs; never in the shipping library
 #include "jcdf_kernels_diag.hpp"
 #include "jcdf_sbr.hpp"
@@ -697,7 +698,7 @@ const DcPlan *dc_plan(int64_t n)
 
 struct DcWork {                      // carve-up of the caller's workspace
     double *w2, *Zb, *X, *Zp, *G, *dl, *zl, *zhat, *mu, *defval, *rho, *sc;
-    int *col, *defcol, *org, *K;
+    int *col, *defcol, *org, *K, *info;
     int64_t ldx, ldzb;
     int64_t bytes;
 };
@@ -709,6 +710,7 @@ DcWork dc_carve(char *base, int64_t n, const DcPlan *plan)
     const int64_t rows = plan->max_rows + 16;
     wk.ldx = roundup(n, 64) + 64;
     wk.ldzb = n;
+    wk.info = (int *)take(256);                      // byte offset 0 of the workspace: non-zero = a leaf's QL iteration did not converge
     wk.w2 = (double *)take(n * 8);
     wk.Zb = (double *)take(n * n * 8);
     wk.X = (double *)take(rows * wk.ldx * 8);
@@ -755,6 +757,10 @@ hipError_t set_device_kernel_attributes()
     set((const void *)k_sp2_fused<Sp2Cfg>, Sp2Cfg::SMEM_BYTES);
     set((const void *)k_sp2_fused<Sp2Cfg64>, Sp2Cfg64::SMEM_BYTES);
     set((const void *)k_blas_gemm_nt, GemmNT<BlasNTCfg>::SMEM_BYTES);
+    set((const void *)k_wy_update, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_wy_U, BlasTNCfg::SMEM_BYTES);
+    set((const void *)k_wy_S, GemmNT<BlasNTCfg>::SMEM_BYTES);
+    set((const void *)k_wy_T, WY_NB * (WY_NB + 1) * 8);
     return first;
 }
 
@@ -1557,6 +1563,25 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     }
     if (lds > 160 * 1024) return JCDF_ERR_INVALID;                   // (reached below the one-exchange limit only by a diagnostic override)
     if (hipFuncSetAttribute((const void *)k_sytrd_lower, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return JCDF_ERR_HIP;
+    if (!d_Q && n > SYTRD_ONEHOP_MAX_N && onehop_env != 0) {
+        // Above the one-exchange kernel's size without Q (round 4; the back-transformation is jcdf_ormtr_device then): the
+        // two-exchange kernel reduces only the first n - 1536 columns (~7 us each) and leaves the trailing 1536 x 1536 block
+        // with every update applied — a symmetric matrix of the size the one-exchange kernel holds (5.7 us per column), which
+        // continues on it in place, followed by the one-workgroup tail: n = 1915 13.5 -> 10.6 ms (profiles/r04_eigh_stages.txt).
+        const int64_t k1 = n - SYTRD_ONEHOP_MAX_N, n2 = SYTRD_ONEHOP_MAX_N;
+        hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(512), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg, hg, err,
+                           (double *)nullptr, 0, (int)k1);
+        // fresh granules for the second kernel (tags restart at 1); the error word in the header stays as the first kernel left it
+        if (hipMemsetAsync(w + 64, 0, (size_t)sytrd_granule_bytes(n) - 64, st) != hipSuccess) return JCDF_ERR_HIP;
+        const int G2 = (int)((n2 + 7) / 8);
+        const size_t lds2 = (size_t)(((n2 + G2 - 1) / G2) * n2 + 5 * n2 + 32) * 8;
+        if (hipFuncSetAttribute((const void *)k_sytrd_onehop<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return JCDF_ERR_HIP;
+        double *A2 = d_A + k1 * (lda + 1);
+        jcdf::u64 *vg2 = (jcdf::u64 *)(w + 64), *yg2 = vg2 + 2 * (n2 + 2), *hg2 = yg2 + 2 * ((n2 + 1) & ~(int64_t)1);
+        hipLaunchKernelGGL(k_sytrd_onehop<48>, dim3((unsigned)G2), dim3(512), lds2, st, A2, (int)lda, (int)n2, d_D + k1, d_E + k1, d_TAU + k1,
+                           vg2, yg2, hg2, err, (double *)nullptr, 0, tail ? (int)(n2 - SYTD2_TAIL_T) : (int)n2);
+        return finish();
+    }
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
     hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
                        hg, err, d_Q, (int)ldq, kstop);
@@ -1604,6 +1629,69 @@ int64_t jcdf_sytrd_max_n(int32_t with_q)
     int64_t n = 64;
     while (sytrd_lds(n + 1, 256, with_q != 0) <= 160 * 1024) ++n;       // the two-exchange kernel (Q rows in LDS)
     return std::max<int64_t>(n, SYTRD_ONEHOP_MAX_N);                     // the one-exchange kernel (Q rows in registers)
+}
+
+// ---- back-transformation by blocked compact-WY on the MFMA cores (jcdf_wy.hpp) ----------------------------------
+namespace {
+struct WyWork {
+    double *Vt, *Ut, *Tm, *Sm, *W;
+    int64_t nrp, npad, nblk, bytes;
+};
+WyWork wy_carve(char *base, int64_t n)
+{
+    WyWork w;
+    w.nrp = roundup(n, WY_NB);
+    w.npad = roundup(n, 32);
+    w.nblk = w.nrp / WY_NB;
+    size_t off = 0;
+    auto take = [&](size_t doubles) { char *p = base ? base + off : nullptr; off += (size_t)roundup((int64_t)doubles * 8, 256); return (double *)p; };
+    w.Vt = take((size_t)w.nrp * w.npad);
+    w.Ut = take((size_t)w.nrp * w.npad);
+    w.Tm = take((size_t)w.nblk * WY_NB * WY_NB);
+    w.Sm = take((size_t)w.nblk * WY_NB * WY_NB);
+    w.W = take((size_t)WY_NB * w.npad);
+    w.bytes = (int64_t)off;
+    return w;
+}
+}  // namespace
+
+int64_t jcdf_ormtr_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    return wy_carve(nullptr, n).bytes;
+}
+
+int32_t jcdf_ormtr_device(void *stream, int64_t n, const double *d_A, int64_t lda, const double *d_TAU, double *d_Ct, int64_t ldc,
+                          double *d_Out, int64_t ldo, void *d_work, int64_t work_bytes)
+{
+    if (n <= 0 || !d_A || lda < n || !d_TAU || !d_Ct || !d_work) return JCDF_ERR_INVALID;
+    WyWork w = wy_carve((char *)d_work, n);
+    if (work_bytes < w.bytes || ldc < w.npad || (ldc & 1) || (d_Out && ldo < w.npad)) return JCDF_ERR_INVALID;
+    if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const int npad = (int)w.npad;
+    hipLaunchKernelGGL(k_wy_extract, dim3((unsigned)((w.nrp * w.npad + 255) / 256)), dim3(256), 0, st, d_A, lda, (int)n, w.Vt, w.npad, (int)w.nrp, npad);
+    hipLaunchKernelGGL(k_wy_S, dim3((unsigned)((WY_NB / 32) * (WY_NB / 32)), (unsigned)w.nblk), dim3(BlasNTCfg::NT), GemmNT<BlasNTCfg>::SMEM_BYTES, st,
+                       (const double *)w.Vt, w.npad, npad, w.Sm);
+    hipLaunchKernelGGL(k_wy_T, dim3((unsigned)w.nblk), dim3(4 * WY_NB), (size_t)WY_NB * (WY_NB + 1) * 8, st, (const double *)w.Sm, d_TAU, (int)n, w.Tm);
+    hipLaunchKernelGGL(k_wy_U, dim3((unsigned)((WY_NB / 32) * (npad / 32)), (unsigned)w.nblk), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st,
+                       (const double *)w.Tm, (const double *)w.Vt, w.npad, npad, w.Ut);
+    for (int64_t b = w.nblk - 1; b >= 0; --b) {
+        const int64_t j0 = b * WY_NB;
+        if (j0 >= n - 2) continue;                                   // a block of identity reflectors
+        const int64_t kq = j0 / 32 * 32;                             // the block's reflectors are zero above row j0 + 1
+        const double *Vb = w.Vt + j0 * w.npad + kq, *Ub = w.Ut + j0 * w.npad + kq;
+        // W[m][j] = sum_k Vt_b[m][k] Zt[j][k]
+        hipLaunchKernelGGL(k_blas_gemm_nt, dim3((unsigned)((WY_NB / 32) * (npad / 32))), dim3(BlasNTCfg::NT), GemmNT<BlasNTCfg>::SMEM_BYTES, st, Vb,
+                           w.npad, (const double *)(d_Ct + kq), ldc, w.W, w.npad, (int)((w.npad - kq) / 16), npad / 32);
+        // Zt[j][k] -= sum_m W[m][j] Ut_b[m][k]
+        const int n_tn = (int)((w.npad - kq) / 32);
+        hipLaunchKernelGGL(k_wy_update, dim3((unsigned)((npad / 32) * n_tn)), dim3(BlasTNCfg::NT), BlasTNCfg::SMEM_BYTES, st, (const double *)w.W, w.npad, Ub,
+                           w.npad, d_Ct + kq, ldc, WY_NB / 32, -1.0, n_tn);
+    }
+    if (d_Out)
+        hipLaunchKernelGGL(k_wy_transpose, dim3((unsigned)(npad / 32), (unsigned)(npad / 32)), dim3(256), 0, st, (const double *)d_Ct, ldc, d_Out, ldo, (int)n);
+    return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
 #ifdef JCDF_DIAGNOSTIC
@@ -1907,11 +1995,21 @@ int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_
     return hipGetLastError() == hipSuccess ? JCDF_OK : JCDF_ERR_HIP;
 }
 
+static size_t dc_prepare_lds(int maxm) { return (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4; }
+
+// the largest merge of the plan must fit k_dc_prepare's LDS (36 bytes per row: n <~ 2700) — checked before anything is enqueued
+static bool dc_plan_fits(const DcPlan *plan)
+{
+    for (const DcLevel &lv : plan->levels)
+        if (dc_prepare_lds(lv.maxm) > (size_t)DC_PREPARE_LDS_MAX) return false;
+    return true;
+}
+
 int64_t jcdf_stedc_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 0;
     const DcPlan *plan = dc_plan(n);
-    if (!plan) return -1;
+    if (!plan || !dc_plan_fits(plan)) return -1;             // too large for this solver: the caller picks another one at construction
     return dc_carve(nullptr, n, plan).bytes;
 }
 
@@ -1921,76 +2019,77 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
     if (n <= 0 || !d_D || !d_Z || ldz < n || (n > 1 && !d_E) || !d_work) return JCDF_ERR_INVALID;
     const DcPlan *plan = dc_plan(n);
     if (!plan) return JCDF_ERR_ALLOC;
+    if (!dc_plan_fits(plan)) return JCDF_ERR_INVALID;                      // before the first launch (jcdf_stedc_workspace_bytes says -1 for such n)
     DcWork wk = dc_carve((char *)d_work, n, plan);
     if (work_bytes < wk.bytes) return JCDF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
+    if (hipMemsetAsync(wk.info, 0, 256, st) != hipSuccess) return JCDF_ERR_HIP;
     const int L = (int)plan->levels.size();
     // ping-pong so that the last level writes into the caller's buffers: eigenvalues end in d_D, vectors in d_Z
     double *Za = (L % 2 == 0) ? d_Z : wk.Zb, *Zn = (L % 2 == 0) ? wk.Zb : d_Z;
     int64_t lda = (L % 2 == 0) ? ldz : wk.ldzb, ldn = (L % 2 == 0) ? wk.ldzb : ldz;
     double *wa = (L % 2 == 0) ? d_D : wk.w2, *wn = (L % 2 == 0) ? wk.w2 : d_D;
     // (wa may be d_D itself: a leaf reads its own diagonal elements, and E, before it writes its eigenvalues over them)
-    hipLaunchKernelGGL(k_dc_norm, dim3(1), dim3(256), 0, st, d_D, d_E, (int)n, wk.sc);
+    hipLaunchKernelGGL(k_dc_norm, dim3(1), dim3(256), 0, st, d_D, d_E, (int)n, wk.sc, wk.info);
     hipLaunchKernelGGL(k_dc_init, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, (int)n, Za, lda, Zn, ldn);
     {
         const int64_t leaves = (n + DC_LEAF - 1) / DC_LEAF;
         hipLaunchKernelGGL(k_dc_leaf, dim3((unsigned)leaves), dim3(64), 0, st, (const double *)d_D,
-                           (const double *)d_E, (int)n, wa, Za, lda, (const double *)wk.sc, L == 0 ? 1 : 0);
+                           (const double *)d_E, (int)n, wa, Za, lda, (const double *)wk.sc, L == 0 ? 1 : 0, wk.info);
     }
     for (int l = 0; l < L; ++l) {
         const DcLevel &lv = plan->levels[l];
         const DcMerge *mg = plan->d_merges + lv.merge_off;
         const int maxm = lv.maxm;
-        const size_t prep_lds = (size_t)(2 * maxm + std::max(maxm, 256)) * 8 + (size_t)3 * maxm * 4;
-        if (prep_lds > DC_PREPARE_LDS_MAX) return JCDF_ERR_INVALID;           // 36 bytes per row of the largest merge: n > ~2700
+        const size_t prep_lds = dc_prepare_lds(maxm);
         static const int fuse_max = diag_env("JCDF_DC_FUSE_MAX") ? atoi(diag_env("JCDF_DC_FUSE_MAX")) : 32;
         if (maxm <= fuse_max) {       // tiny merges: one launch per level instead of six
             hipLaunchKernelGGL(k_dc_merge_small<4>, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
                                wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc, wk.org, wk.mu, wk.zhat, wk.X, wk.Zp, wk.ldx, wk.G, Zn,
-                               ldn, wn, l == L - 1 ? 1 : 0);
+                               ldn, wn, l == L - 1 ? 1 : 0, (const int *)wk.info);
         } else {
             hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)lv.nm), dim3(256), prep_lds, st, mg, wa, d_E, Za, lda, wk.K, wk.rho,
-                               wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc);
+                               wk.dl, wk.zl, wk.col, wk.defcol, wk.defval, wk.sc, (const int *)wk.info);
             // lanes per root / per zhat entry: enough workgroups at the big levels, no idle lanes at the small ones
             const unsigned nmu = (unsigned)lv.nm;
             if (maxm >= 256) {
                 const unsigned gx = (unsigned)((maxm + 3) / 4);                   // 4 roots (64 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-                hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+                hipLaunchKernelGGL(k_dc_secular<64>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu, (const int *)wk.info);
+                hipLaunchKernelGGL(k_dc_zhat<64>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat, (const int *)wk.info);
             } else if (maxm >= 64) {
                 const unsigned gx = (unsigned)((maxm + 15) / 16);                 // 16 roots (16 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-                hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+                hipLaunchKernelGGL(k_dc_secular<16>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu, (const int *)wk.info);
+                hipLaunchKernelGGL(k_dc_zhat<16>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat, (const int *)wk.info);
             } else {
                 const unsigned gx = (unsigned)std::max(1, (maxm + 63) / 64);      // 64 roots (4 lanes each) per block
-                hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu);
-                hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat);
+                hipLaunchKernelGGL(k_dc_secular<4>, dim3(gx, nmu), dim3(256), (size_t)2 * maxm * 8, st, mg, wk.K, wk.rho, wk.dl, wk.zl, wk.org, wk.mu, (const int *)wk.info);
+                hipLaunchKernelGGL(k_dc_zhat<4>, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.zl, wk.org, wk.mu, wk.zhat, (const int *)wk.info);
             }
             {
                 const int64_t work = (int64_t)roundup(maxm, 16) * (roundup(maxm, 16) + maxm);
                 const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, lv.nm) + 1, (work + 1023) / 1024));
                 hipLaunchKernelGGL(k_dc_vectors, dim3(gx, nmu), dim3(256), 0, st, mg, wk.K, wk.dl, wk.org, wk.mu, wk.zhat, wk.col, Za, lda,
-                                   wk.X, wk.Zp, wk.ldx, maxm >= DC_MFMA_MIN ? 1 : 0);
+                                   wk.X, wk.Zp, wk.ldx, maxm >= DC_MFMA_MIN ? 1 : 0, (const int *)wk.info);
             }
             if (maxm >= DC_MFMA_MIN) {
                 const unsigned tiles = (unsigned)(((maxm + 63) / 64) * ((maxm + 63) / 64));
                 if ((int64_t)tiles * lv.nm < 128) {          // too few 64 x 64 tiles to fill the chip: 32 x 32
                     const unsigned t32 = (unsigned)(((maxm + 31) / 32) * ((maxm + 31) / 32));
                     hipLaunchKernelGGL(k_dc_update_mfma<DcCfg32>, dim3(t32, (unsigned)lv.nm), dim3(DcCfg32::NT), DcCfg32::SMEM_BYTES, st, mg,
-                                       wk.K, wk.X, wk.Zp, wk.ldx, wk.G);
+                                       wk.K, wk.X, wk.Zp, wk.ldx, wk.G, (const int *)wk.info);
                 } else {
                     hipLaunchKernelGGL(k_dc_update_mfma<DcCfg>, dim3(tiles, (unsigned)lv.nm), dim3(DcCfg::NT), DcCfg::SMEM_BYTES, st, mg, wk.K,
-                                       wk.X, wk.Zp, wk.ldx, wk.G);
+                                       wk.X, wk.Zp, wk.ldx, wk.G, (const int *)wk.info);
                 }
             } else {
                 const unsigned tiles = (unsigned)std::min(64, ((maxm + 15) / 16) * ((maxm + 15) / 16));
                 hipLaunchKernelGGL(k_dc_update_simple, dim3(tiles, (unsigned)lv.nm), dim3(256), 0, st, mg, wk.K, wk.X, wk.Zp, wk.ldx,
-                                   wk.G);
+                                   wk.G, (const int *)wk.info);
             }
             const unsigned fx = (unsigned)std::max(1, (maxm + 7) / 8);
             hipLaunchKernelGGL(k_dc_finish, dim3(fx, (unsigned)lv.nm), dim3(256), (size_t)maxm * 8, st, mg, wk.K, wk.dl, wk.org, wk.mu,
-                               wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn, wk.sc, l == L - 1 ? 1 : 0);
+                               wk.defcol, wk.defval, wk.G, wk.ldx, Za, lda, Zn, ldn, wn, wk.sc, l == L - 1 ? 1 : 0, (const int *)wk.info);
         }
         if (lv.has_carry)
             hipLaunchKernelGGL(k_dc_carry, dim3(16, 1), dim3(256), 0, st, mg + lv.nm, Za, lda, Zn, ldn, wa, wn);

@@ -43,13 +43,21 @@ __device__ __forceinline__ double dc_ld(const double *p)
 // ---- scaling (LAPACK dstedc scales to unit max-norm: the tolerances and products below assume O(1) data) --
 // sc[0] = max(|d|, |e|) (1 for the zero matrix), sc[1] = 1/sc[0].  One workgroup.
 __global__ __launch_bounds__(256) void k_dc_norm(const double *__restrict__ d, const double *__restrict__ e, int n,
-                                                 double *__restrict__ sc)
+                                                 double *__restrict__ sc, int *__restrict__ info)
 {
     __shared__ double red[256];
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
     double mx = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) mx = fmax(mx, fmax(fabs(d[i]), i < n - 1 ? fabs(e[i]) : 0.0));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double di = d[i], ei = i < n - 1 ? e[i] : 0.0;
+        if (!(fabs(di) <= 1.79e308) || !(fabs(ei) <= 1.79e308)) bad = 1;        // NaN / Inf (fmax below would skip a NaN)
+        mx = fmax(mx, fmax(fabs(di), fabs(ei)));
+    }
     red[threadIdx.x] = mx;
     __syncthreads();
+    if (threadIdx.x == 0 && bad) *info = 2;             // every later kernel of this call returns at once (k_dc_leaf included)
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
         __syncthreads();
@@ -85,13 +93,13 @@ __global__ void k_dc_init(int n, double *__restrict__ Z, int64_t ldz, double *__
 // Out: w[s + k] ascending, row s + k of Z = eigenvector k (components in columns s ..).
 constexpr int DC_LEAF = 8;
 __global__ __launch_bounds__(64) void k_dc_leaf(const double *__restrict__ d, const double *__restrict__ e, int n, double *__restrict__ w,
-                                                double *__restrict__ Z, int64_t ldz, const double *__restrict__ sc, int last)
+                                                double *__restrict__ Z, int64_t ldz, const double *__restrict__ sc, int last, int *__restrict__ info)
 {
     __shared__ double sd[DC_LEAF][DC_LEAF], se[DC_LEAF][DC_LEAF], sz[DC_LEAF][DC_LEAF];
     const int lane = threadIdx.x, r = lane;
     const int s = blockIdx.x * DC_LEAF;
     const int m = n - s < DC_LEAF ? n - s : DC_LEAF;
-    if (m <= 0 || lane >= DC_LEAF) return;
+    if (m <= 0 || lane >= DC_LEAF || *info == 2) return;
     const double scale = sc[1];
     for (int i = 0; i < DC_LEAF; ++i) {
         double di = 0.0, ei = 0.0;
@@ -118,7 +126,10 @@ __global__ __launch_bounds__(64) void k_dc_leaf(const double *__restrict__ d, co
                 mm = hit ? (int)__builtin_ctzll(hit) : m - 1;
             }
             if (mm != l) {
-                if (iter++ == 60) break;                  // (never seen; the merges above would then deflate garbage, so stop here)
+                if (iter++ == 60) {                       // never seen on finite input; NaN input ends here (`small` is never true):
+                    if (lane == 0) *info = 1;             // reported — the caller must not use this decomposition (jcdf.h: stedc info word)
+                    break;
+                }
                 const double el = se[l][lane], dl = sd[l][lane];
                 // Wilkinson shift (reciprocals and the root by estimate + two Newton steps, as in the rotations below)
                 auto recip = [](double x) { double y = __builtin_amdgcn_rcp(x); y = y * (2.0 - x * y); return y * (2.0 - x * y); };
@@ -351,8 +362,9 @@ __global__ __launch_bounds__(256) void k_dc_prepare(const DcMerge *__restrict__ 
                                                     int *__restrict__ Kout, double *__restrict__ rho_out,
                                                     double *__restrict__ dl, double *__restrict__ zl, int *__restrict__ col,
                                                     int *__restrict__ defcol, double *__restrict__ defval,
-                                                    const double *__restrict__ sc)
+                                                    const double *__restrict__ sc, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_prepare_body(merges, w, e, Z, ldz, Kout, rho_out, dl, zl, col, defcol, defval, sc, (int)blockIdx.x, 0, 1, dyn_smem);
 }
@@ -501,8 +513,9 @@ template <int LANES>
 __global__ __launch_bounds__(256) void k_dc_secular(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                     const double *__restrict__ rho_in, const double *__restrict__ dl,
                                                     const double *__restrict__ zl, int *__restrict__ org,
-                                                    double *__restrict__ mu)
+                                                    double *__restrict__ mu, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_secular_body<LANES>(merges, Kin, rho_in, dl, zl, org, mu, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
@@ -540,8 +553,9 @@ template <int LANES>
 __global__ __launch_bounds__(256) void k_dc_zhat(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                  const double *__restrict__ dl, const double *__restrict__ zl,
                                                  const int *__restrict__ org, const double *__restrict__ mu,
-                                                 double *__restrict__ zhat)
+                                                 double *__restrict__ zhat, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_zhat_body<LANES>(merges, Kin, dl, zl, org, mu, zhat, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
@@ -578,8 +592,9 @@ __global__ __launch_bounds__(256) void k_dc_vectors(const DcMerge *__restrict__ 
                                                     const double *__restrict__ dl, const int *__restrict__ org,
                                                     const double *__restrict__ mu, const double *__restrict__ zhat,
                                                     const int *__restrict__ col, const double *__restrict__ Z, int64_t ldz,
-                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx, int pad16)
+                                                    double *__restrict__ X, double *__restrict__ Zp, int64_t ldx, int pad16, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_vectors_body(merges, Kin, dl, org, mu, zhat, col, Z, ldz, X, Zp, ldx, pad16, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
@@ -614,8 +629,9 @@ __device__ __forceinline__ void dc_update_simple_body(const DcMerge *__restrict_
 
 __global__ __launch_bounds__(256) void k_dc_update_simple(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                           const double *__restrict__ X, const double *__restrict__ Zp,
-                                                          int64_t ldx, double *__restrict__ Gm)
+                                                          int64_t ldx, double *__restrict__ Gm, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_update_simple_body(merges, Kin, X, Zp, ldx, Gm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
@@ -628,8 +644,9 @@ using DcCfg32 = GemmCfg<1, 1, 2, 2, 16>;
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_dc_update_mfma(const DcMerge *__restrict__ merges, const int *__restrict__ Kin,
                                                         const double *__restrict__ X, const double *__restrict__ Zp,
-                                                        int64_t ldx, double *__restrict__ Gm)
+                                                        int64_t ldx, double *__restrict__ Gm, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     constexpr int T = Cfg::TM;
     static_assert(Cfg::TM == Cfg::TN, "square tiles");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -705,8 +722,9 @@ __global__ __launch_bounds__(256) void k_dc_finish(const DcMerge *__restrict__ m
                                                    const double *__restrict__ defval, const double *__restrict__ Gm,
                                                    int64_t ldx, const double *__restrict__ Z, int64_t ldz_in,
                                                    double *__restrict__ Znew, int64_t ldz, double *__restrict__ wnew,
-                                                   const double *__restrict__ sc, int last)
+                                                   const double *__restrict__ sc, int last, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     dc_finish_body(merges, Kin, dl, org, mu, defcol, defval, Gm, ldx, Z, ldz_in, Znew, ldz, wnew, sc, last, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, dyn_smem);
 }
@@ -719,8 +737,9 @@ __global__ __launch_bounds__(256) void k_dc_merge_small(const DcMerge *merges, d
                                                         int *Kbuf, double *rho, double *dl, double *zl, int *col, int *defcol,
                                                         double *defval, const double *sc, int *org, double *mu, double *zhat,
                                                         double *X, double *Zp, int64_t ldx, double *G, double *Znew, int64_t ldzn,
-                                                        double *wnew, int last)
+                                                        double *wnew, int last, const int *__restrict__ dc_info)
 {
+    if (*dc_info) return;      // non-finite input / a leaf that did not converge (jcdf.h: stedc info word): nothing downstream may index with it
     extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
     const int mi = blockIdx.x;
     dc_prepare_body(merges, w, e, Z, ldz, Kbuf, rho, dl, zl, col, defcol, defval, sc, mi, 0, 1, dyn_smem);

@@ -2,15 +2,17 @@
 SURVEY 8 row f1; reference: `eigen!(Hermitian(F'))`, SCF.jl:1083).
 
 rocSOLVER's syevd needs ~4000 tiny launches for the tridiagonalisation (9 of its 12 ms at
-N = 510).  Here the tridiagonalisation is ONE persistent kernel of libjcdf_hip.so
-(`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp: one hand-off per column up to N = 640, two above) which also accumulates the orthogonal factor Q while
-its reflectors travel between workgroups (A = Q T Q^T), so the back-transformation is one GEMM
-Q Z instead of LAPACK's ormtr (~30 launches, 1.1 ms).  The tridiagonal eigenproblem is solved by
-the library's own divide & conquer (`jcdf_stedc_device`, csrc/jcdf_dc.hpp: 1.0 ms at N = 510 where
-rocSOLVER's stedc takes 2.6 ms).  JCDF_EIGH_VENDOR_STEDC=1 / JCDF_EIGH_ORMTR=1 select the vendor
-routines already in the process (PyTorch's librocsolver) for those two steps; matrices too large for
-Q to stay in LDS use ormtr.  Falls back to torch.linalg.eigh when an in-kernel hand-off reports a
-timeout.
+N = 510).  Here every stage is the library's own (libjcdf_hip.so; no vendor kernel on the path):
+  * tridiagonalisation: ONE persistent kernel (`jcdf_sytrd_q_device`, csrc/jcdf_eig.hpp) + a one-workgroup finish for the
+    last 128 columns; up to n = 1536 it also accumulates the orthogonal factor Q while its reflectors travel between
+    workgroups (A = Q T Q^T), so the back-transformation is one GEMM Q Z;
+  * tridiagonal eigenproblem: divide & conquer (`jcdf_stedc_device`, csrc/jcdf_dc.hpp: 1.0 ms at N = 510 where
+    rocSOLVER's stedc takes 2.6 ms);
+  * above n = 1536 (rows of Q no longer fit a workgroup's registers): the first n - 1536 columns through the two-exchange
+    kernel, the trailing block through the one-exchange kernel, and the eigenvectors by blocked compact-WY on the MFMA cores
+    (`jcdf_ormtr_device`, csrc/jcdf_wy.hpp) — round 3 called rocsolver_dormtr there.
+JCDF_EIGH_WY=1 forces the compact-WY back-transformation at every size (tests).  When an in-kernel hand-off reports a
+timeout or a stage fails, the step is redone with torch.linalg.eigh (counted in `fallbacks`, never silent).
 """
 from __future__ import annotations
 
@@ -23,10 +25,6 @@ import torch
 from . import _lib
 
 TWO_STAGE_DEFAULT = False     # the two-stage reduction measured at parity (profiles/r02_two_stage_eigh.txt): diagnostic builds only
-_EVECT_TRIDIAGONAL = 212      # rocblas_evect_tridiagonal
-_SIDE_LEFT = 141              # rocblas_side_left
-_FILL_LOWER = 122             # rocblas_fill_lower
-_OP_NONE = 111                # rocblas_operation_none
 
 
 class DeviceEigh:
@@ -39,38 +37,34 @@ class DeviceEigh:
         self.timing = False            # True: device events around the tridiagonalisation and the tridiagonal solver of every call
         self.stage_events = []         # [(e0, e1, e2)] per call while `timing`; read with stage_ms()
         try:
-            tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-            self.rb = C.CDLL(os.path.join(tl, "librocblas.so"))
-            self.rs = C.CDLL(os.path.join(tl, "librocsolver.so"))
             self.lib = _lib.load()
-            self.handle = C.c_void_p()
-            if self.rb.rocblas_create_handle(C.byref(self.handle)) != 0:
-                raise OSError("rocblas_create_handle failed")
             f64 = dict(dtype=torch.float64, device=device)
             self.A = torch.empty((n, n), **f64)
-            self.Cm = torch.empty((n, n), **f64)
             self.D = torch.empty(n, **f64)
             self.E = torch.empty(n, **f64)
-            self.TAU = torch.empty(n, **f64)
-            self.info = torch.zeros(1, dtype=torch.int32, device=device)
+            self.TAU = torch.zeros(n, **f64)
+            self.info = torch.zeros(1, dtype=torch.int32, device=device)     # (kept for callers that fold it into their status word)
             wb = int(self.lib.jcdf_sytrd_workspace_bytes(n))
             self.work = torch.zeros(wb // 8 + 1, **f64)
             self.wb = wb
-            self.with_q = n <= int(self.lib.jcdf_sytrd_max_n(1)) and not os.environ.get("JCDF_EIGH_ORMTR")
-            self.Q = torch.empty((n, n), **f64) if self.with_q else None
-            # back-transformation U = Q Z on the library's NT MFMA core: operands with a leading dimension that is a
-            # multiple of 32 and zero padding (jcdf_gemm_nt_device); Zt[j][k] = Z[k][j] is what stedc writes with ldz = npad
+            if n > int(self.lib.jcdf_sytrd_max_n(0)):
+                raise OSError("n = %d is above the tridiagonalisation kernels' limit of %d" % (n, int(self.lib.jcdf_sytrd_max_n(0))))
+            self.with_q = n <= int(self.lib.jcdf_sytrd_max_n(1)) and not os.environ.get("JCDF_EIGH_WY")
+            # operands of the library's GEMM cores: leading dimension a multiple of 32, zero padding; Zt[j][k] = Z[k][j] is what
+            # stedc writes with ldz = npad
             self.npad = (n + 31) // 32 * 32
             self.Qp = torch.zeros((self.npad, self.npad), **f64) if self.with_q else None
             self.Zt = torch.zeros((self.npad, self.npad), **f64)
             self.Up = torch.zeros((self.npad, self.npad), **f64)
-            self.own_stedc = not os.environ.get("JCDF_EIGH_VENDOR_STEDC")
+            if not self.with_q:
+                self.wy_wb = int(self.lib.jcdf_ormtr_workspace_bytes(n))
+                self.wy_work = torch.zeros(self.wy_wb // 8 + 8, **f64)
             # two-stage reduction (dense -> band -> tridiagonal, csrc/jcdf_sbr.hpp) where the band fits the LDS of one CU;
             # its Q replay runs on a side stream beside the tridiagonal solver.  JCDF_EIGH_TWO_STAGE=0/1 overrides.
             # (DIAGNOSTIC builds of the library only — the product library does not contain these entry points)
             diag = hasattr(self.lib, "jcdf_sytrd2_device")
             ts = os.environ.get("JCDF_EIGH_TWO_STAGE")
-            self.two_stage = (diag and self.with_q and self.own_stedc and 3 <= n <= int(self.lib.jcdf_sytrd2_max_n())
+            self.two_stage = (diag and self.with_q and 3 <= n <= int(self.lib.jcdf_sytrd2_max_n())
                               and (ts == "1" if ts is not None else TWO_STAGE_DEFAULT))
             if self.two_stage:
                 self.wb2 = int(self.lib.jcdf_sytrd2_workspace_bytes(n))
@@ -78,19 +72,18 @@ class DeviceEigh:
             # JCDF_EIGH_Q_REPLAY=1 (one-stage kernel, n <= 640): Q rebuilt from the stored reflectors on a side stream beside the
             # divide & conquer instead of inside the persistent kernel — measured equal inside the SCF loop (the kernel's hand-off
             # window, not the Q update inside it, sets the time of a column), so the in-kernel accumulation stays the default
-            self.q_replay = (diag and self.with_q and self.own_stedc and not self.two_stage and n <= 640
+            self.q_replay = (diag and self.with_q and not self.two_stage and n <= 640
                              and os.environ.get("JCDF_EIGH_Q_REPLAY") == "1")
             if self.two_stage or self.q_replay:
                 self.side = torch.cuda.Stream(device=device)
                 self.ev_fork = torch.cuda.Event()
                 self.ev_join = torch.cuda.Event()
-            if self.own_stedc:
-                self.dc_wb = int(self.lib.jcdf_stedc_workspace_bytes(n))
-                if self.dc_wb < 0:
-                    raise OSError("jcdf_stedc_workspace_bytes failed")
-                self.dc_work = torch.empty(self.dc_wb // 8 + 8, **f64)
+            self.dc_wb = int(self.lib.jcdf_stedc_workspace_bytes(n))
+            if self.dc_wb < 0:
+                raise OSError("jcdf_stedc_workspace_bytes(%d) = -1: too large for the library's divide & conquer" % n)
+            self.dc_work = torch.zeros(self.dc_wb // 8 + 8, **f64)
             self.ok = True
-        except Exception as e:                                    # vendor library not loadable: plain torch path
+        except Exception as e:                                    # library not loadable / size outside its kernels: plain torch path
             self.reason = repr(e)
 
     def __call__(self, Fp: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -100,54 +93,45 @@ class DeviceEigh:
         self.U_padded = None                                      # set when U was produced zero padded (npad x npad) by the library
         if not self.ok:                                           # counted in `fallbacks` when the switch happened; see `reason`
             return torch.linalg.eigh(Fp)
-        n = self.n
+        n, npad = self.n, self.npad
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self.rb.rocblas_set_stream(self.handle, C.c_void_p(st))
         p = lambda t: C.c_void_p(t.data_ptr())
         if self.two_stage or self.q_replay:
             self.A.copy_(Fp)
             return self._two_stage(Fp, st, p) if self.two_stage else self._one_stage_replay(Fp, st, p)
-        own_gemm = self.with_q and self.own_stedc
         # `scratch`: the caller hands over a work matrix it no longer needs (row stride = its leading dimension): tridiagonalised
         # in place, no copy; Q goes straight into the zero padded operand of the back-transformation GEMM
-        if self.scratch and own_gemm and Fp.stride(1) == 1:
+        in_place = self.scratch and Fp.stride(1) == 1
+        if in_place:
             A, lda = Fp, Fp.stride(0)
         else:
             self.A.copy_(Fp)
             A, lda = self.A, n
         ev = self._stamp(None)
         rc = self.lib.jcdf_sytrd_q_device(C.c_void_p(st), n, p(A), lda, p(self.D), p(self.E), p(self.TAU),
-                                          (p(self.Qp) if own_gemm else p(self.Q)) if self.with_q else None, self.npad if own_gemm else n,
-                                          p(self.work), self.wb)
+                                          p(self.Qp) if self.with_q else None, npad, p(self.work), self.wb)
         ev = self._stamp(ev)
-        if rc == 0 and self.own_stedc:
-            zt, ldz = (self.Zt, self.npad) if own_gemm else (self.Cm, n)
-            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(zt), ldz, p(self.dc_work),
-                                            self.dc_wb)
-        elif rc == 0:
-            rc = self.rs.rocsolver_dstedc(self.handle, _EVECT_TRIDIAGONAL, n, p(self.D), p(self.E), p(self.Cm), n,
-                                          p(self.info))
-        ev = self._stamp(ev)
-        if rc == 0 and own_gemm:
-            # U[m][j] = sum_k Q[m][k] Z[k][j] = sum_k Qp[m][k] Zt[j][k]: the NT core; U comes back zero padded (npad x npad)
-            rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), self.npad, self.npad, self.npad, p(self.Qp), self.npad, p(self.Zt),
-                                              self.npad, p(self.Up), self.npad)
-            if rc == 0:
-                self.U_padded = self.Up
-                return self.D, self.Up[:n, :n]
-        if rc == 0 and self.with_q:
-            # Cm holds Z column-major == Z^T as a row-major tensor; Q is row-major: U = Q Z
-            return self.D, self.Q @ self.Cm.T
         if rc == 0:
-            rc = self.rs.rocsolver_dormtr(self.handle, _SIDE_LEFT, _FILL_LOWER, _OP_NONE, n, n, p(self.A), n,
-                                          p(self.TAU), p(self.Cm), n)
+            rc = self.lib.jcdf_stedc_device(C.c_void_p(st), n, p(self.D), p(self.E), p(self.Zt), npad, p(self.dc_work), self.dc_wb)
+        ev = self._stamp(ev)
+        if rc == 0 and self.with_q:
+            # U[m][j] = sum_k Q[m][k] Z[k][j] = sum_k Qp[m][k] Zt[j][k]: the NT core; U comes back zero padded (npad x npad)
+            rc = self.lib.jcdf_gemm_nt_device(C.c_void_p(st), npad, npad, npad, p(self.Qp), npad, p(self.Zt), npad, p(self.Up), npad)
+        elif rc == 0:
+            # Z <- Q Z from the stored reflectors (blocked compact-WY on the MFMA cores), U = its transpose-free copy in Up
+            rc = self.lib.jcdf_ormtr_device(C.c_void_p(st), n, p(A), lda, p(self.TAU), p(self.Zt), npad, p(self.Up), npad,
+                                            p(self.wy_work), self.wy_wb)
         if rc != 0:
+            # the kernels of a stage may already have run on the caller's matrix (`scratch`): an eigensolve of what is left of it
+            # would be silently wrong — that caller rebuilds its matrix and calls again (DeviceSCF: check() -> _diag)
             self.ok = False
-            self.reason = "vendor/library call failed rc=%d" % rc
+            self.reason = "library call failed rc=%d" % rc
             self.fallbacks += 1
+            if in_place:
+                raise RuntimeError("DeviceEigh: %s after the caller's matrix was overwritten (scratch): rebuild it and call again" % self.reason)
             return torch.linalg.eigh(Fp)
-        # column-major eigenvector matrix == transpose of the row-major view
-        return self.D, self.Cm.T
+        self.U_padded = self.Up
+        return self.D, self.Up[:n, :n]
 
     def _stamp(self, ev):
         """timing only: one more device event on the current stream (ev = None starts a call's record)"""
@@ -221,31 +205,36 @@ class DeviceEigh:
         w = self.work2 if self.two_stage else self.work
         return w[1:2].view(torch.int32)[0:1]
 
+    def _dc_info(self) -> torch.Tensor:
+        """1-element int32 view of the divide & conquer's info word (byte 0 of its workspace: a leaf that did not converge)"""
+        return self.dc_work[0:1].view(torch.int32)[0:1]
+
     def status(self) -> torch.Tensor:
-        """0-d float64 device tensor, non-zero iff the last call failed (hand-off timeout in the tridiagonalisation or
-        a vendor stedc failure) — for callers that fold it into a device-to-host copy they make anyway."""
+        """0-d float64 device tensor, non-zero iff the last call failed (hand-off timeout in the tridiagonalisation or a
+        tridiagonal leaf that did not converge) — for callers that fold it into a device-to-host copy they make anyway."""
         if not self.ok:
             return torch.zeros((), dtype=torch.float64, device=self.device)
-        return (self._err_word()[0].abs() + self.info[0].abs()).to(torch.float64)
+        return (self._err_word()[0].abs() + self._dc_info()[0].abs()).to(torch.float64)
 
     def status_tensors(self):
-        """(int32 error word of the tridiagonalisation, int32 info of a vendor stedc) as 1-element device views, or
+        """(int32 error word of the tridiagonalisation, int32 info word of the divide & conquer) as 1-element device views, or
         (None, None) when the plain torch path is in use — for `jcdf_scf_tail_device`."""
         if not self.ok:
             return None, None
-        return self._err_word(), self.info
+        return self._err_word(), self._dc_info()
 
     def check(self) -> bool:
-        """True if the persistent kernel's grid barrier never timed out and stedc converged
+        """True if the persistent kernel's hand-offs never timed out and the divide & conquer converged
         (reads two words from the device: call where the stream is synchronised anyway)."""
         if not self.ok:
             return True
         err = int(self._err_word()[0].item())                       # int at byte offset 8
-        bad = err != 0 or int(self.info.item()) != 0
+        info = int(self._dc_info()[0].item())
+        bad = err != 0 or info != 0
         if bad:
             self.ok = False
             self.fallbacks += 1
-            self.reason = "sytrd barrier timeout" if err else "stedc info=%d" % int(self.info.item())
+            self.reason = "sytrd hand-off timeout" if err else "stedc info=%d" % info
         return not bad
 
 

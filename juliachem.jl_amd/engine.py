@@ -353,7 +353,13 @@ class DeviceSCF:
         self._f64 = dict(dtype=torch.float64, device=dev)
         self.Hp = self._padded(H)
         self.Sp = self._padded(S)
-        s, U = torch.linalg.eigh(self.Sp[:self.N, :self.N])          # once per SCF (setup): vendor eigensolver
+        self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM / compact-WY
+        # X = U s^-1/2 U^T (SCF.jl:142-162) from the library's own eigensolver as well (round 3: torch.linalg.eigh here);
+        # a failure of it is counted like any other (solver_report) and the vendor routine takes this one decomposition
+        s, U = self.eigh(self.Sp[:self.N, :self.N])
+        if not self.eigh.check():
+            s, U = torch.linalg.eigh(self.Sp[:self.N, :self.N])
+        s, U = s.clone(), U.clone()
         keep = s >= 1.0e-6                                          # SCF.jl:142-162
         self.Xp = self._padded((U[:, keep] * s[keep].rsqrt()) @ U[:, keep].T)
         self.E_nuc = E_nuc
@@ -362,7 +368,6 @@ class DeviceSCF:
             # (jcdf_diis_device: at most 15 vectors); the reference's default is 10 (SCF.jl:364)
             raise ValueError("ndiis = %r: the device DIIS keeps 0..15 error vectors" % (ndiis,))
         self.ndiis = int(ndiis)
-        self.eigh = DeviceEigh(self.N, dev)      # persistent-kernel tridiagonalisation + divide & conquer + one GEMM
         self.density_solver = (os.environ.get("JCDF_DENSITY_SOLVER") or density_solver or "eigh").lower()
         if self.density_solver not in ("eigh", "sp2"):
             raise ValueError("density_solver %r: \"eigh\" or \"sp2\"" % self.density_solver)
@@ -502,7 +507,14 @@ class DeviceSCF:
             self._sp2_basis()
             return
         else:
-            self.eps, U = self.eigh(self.Fpr[:N, :N])               # (destroys Fpr: eigh.scratch)
+            try:
+                self.eps, U = self.eigh(self.Fpr[:N, :N])           # (destroys Fpr: eigh.scratch)
+            except RuntimeError:
+                # a stage of the library failed after X F X had been overwritten: rebuild it; the eigensolver has switched to
+                # the vendor routine (counted in solver_report), which leaves its argument alone
+                self._gemm_tn(self.Fp_, self.Xp, self.T1)
+                self._gemm_tn(self.Xp, self.T1, self.Fpr)
+                self.eps, U = self.eigh(self.Fpr[:N, :N])
             Up = self.eigh.U_padded                                 # the library path leaves U zero padded (Np x Np) already
             if Up is None:
                 self.Up[:N, :N].copy_(U)

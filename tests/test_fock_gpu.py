@@ -409,18 +409,19 @@ def test_water_golden_energy_trail_on_gpu():
     fb.close()
 
 
-@pytest.mark.parametrize("n,ormtr", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
-                                     (956, 0), (1000, 0), (1001, 0), (1250, 0), (1536, 0), (1537, 0), (1700, 0), (1915, 0), (64, 1), (130, 1), (510, 1),
-                                     (1600, 1), (64, 2), (510, 2)])      # (n > 1536: the two-exchange kernel k_sytrd_lower)
-def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
-    """Persistent-kernel tridiagonalisation (+ in-kernel Q accumulation and one GEMM, or ormtr) + stedc
-    vs numpy (LAPACK) eigh."""
+@pytest.mark.parametrize("n,wy", [(1, 0), (2, 0), (3, 0), (25, 0), (64, 0), (130, 0), (257, 0), (510, 0), (700, 0),
+                                  (956, 0), (1000, 0), (1001, 0), (1250, 0), (1536, 0), (1537, 0), (1700, 0), (1915, 0), (2040, 0),
+                                  (3, 1), (25, 1), (64, 1), (65, 1), (130, 1), (257, 1), (510, 1), (1250, 1)])
+def test_device_eigh_matches_lapack(n, wy, monkeypatch):
+    """Persistent-kernel tridiagonalisation + divide & conquer + back-transformation vs numpy (LAPACK) eigh.  Up to n = 1536 Q is
+    accumulated in the kernel and the eigenvectors are one GEMM; above (1537, 1700, 1915 = the gly10 size of BASELINE config 5,
+    2040 = the largest size of the kernels) the first columns go through the two-exchange kernel, the trailing block through the
+    one-exchange kernel, and the eigenvectors come from the stored reflectors by blocked compact-WY (jcdf_ormtr_device) — no
+    vendor kernel at any size.  wy = 1 forces that back-transformation at small sizes too (every block / padding edge of it)."""
     import torch
     from juliachem_jl_amd.eigh import DeviceEigh
-    if ormtr == 1:
-        monkeypatch.setenv("JCDF_EIGH_ORMTR", "1")
-    if ormtr == 2:                                # vendor stedc instead of the library's divide & conquer
-        monkeypatch.setenv("JCDF_EIGH_VENDOR_STEDC", "1")
+    if wy == 1:
+        monkeypatch.setenv("JCDF_EIGH_WY", "1")
     rng = np.random.default_rng(n)
     A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
     if n == 64:                                   # degenerate spectrum + zero sub-columns (tau == 0 branches)
@@ -428,9 +429,8 @@ def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     dev = torch.device("cuda", 0)
     eg = DeviceEigh(n, dev)
     assert eg.ok, getattr(eg, "reason", "")
-    # (Q is accumulated in the kernel up to n = 1536, the one-exchange kernel's limit; above, the two-exchange kernel leaves the
-    #  reflectors to the vendor's ormtr: its rows of Q would not fit the LDS beside the matrix)
-    assert eg.with_q == (ormtr != 1 and n <= 1536) and eg.own_stedc == (ormtr != 2)
+    assert eg.with_q == (wy != 1 and n <= 1536)
+    assert not hasattr(eg, "rs") and not hasattr(eg, "rb")         # no rocSOLVER / rocBLAS handle any more
     w, U = eg(torch.as_tensor(A, device=dev))
     torch.cuda.synchronize()
     assert eg.check() and eg.fallbacks == 0, getattr(eg, "reason", "")
@@ -440,6 +440,26 @@ def test_device_eigh_matches_lapack(n, ormtr, monkeypatch):
     assert np.abs(w - wref).max() < 1e-12 * scale * n
     assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 * n
     assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * scale * n
+
+
+def test_device_eigh_reports_non_finite_input_and_sizes_outside_its_kernels():
+    """a tridiagonal leaf whose QL iteration hits its cap (NaN input does) sets the divide & conquer's info word,
+    so check() fails and the caller redoes the step; sizes the kernels cannot hold are known at construction
+    (jcdf_stedc_workspace_bytes = -1 / the tridiagonalisation's limit), not after a partial run."""
+    import torch
+    from juliachem_jl_amd import _lib
+    from juliachem_jl_amd.eigh import DeviceEigh
+    dev = torch.device("cuda", 0)
+    n = 96
+    A = np.eye(n); A[5, 7] = A[7, 5] = np.nan
+    eg = DeviceEigh(n, dev)
+    eg(torch.as_tensor(A, device=dev))
+    torch.cuda.synchronize()
+    assert not eg.check() and eg.fallbacks == 1 and not eg.ok
+    lib = _lib.load()
+    assert lib.jcdf_stedc_workspace_bytes(3000) == -1 and lib.jcdf_stedc_workspace_bytes(2040) > 0
+    big = DeviceEigh(2100, dev)
+    assert not big.ok and "limit" in big.reason
 
 
 @pytest.mark.parametrize("n", [31, 47, 128, 129, 200, 300])
