@@ -115,6 +115,9 @@ int32_t jcdf_configure(jcdf_handle *h, int64_t N, int64_t Q_total, int64_t q0, i
  *                       GPUDF.jl:61-72; results do not depend on it beyond summation order)
  *   "w_chunk_stages"    contraction stages per workgroup chunk of the exchange-W kernel
  *   "host_cholesky"     1: factor the metric with the library's host potrf/trtri instead of on the device
+ *   "j_workgroups"      workgroups of the Coulomb pass while it runs beside the exchange-K pass (library rule: one per CU
+ *                       while K is the longer kernel; results do not depend on it)
+ *   "k_first"           1: enqueue K in front of J in that phase (library rule: J first)
  * JCDF_ERR_INVALID for an unknown key or a value out of range. */
 int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value);
 
@@ -235,6 +238,15 @@ int32_t jcdf_sytrd_device(void *stream, int64_t n, double *d_A, int64_t lda, dou
 int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, double *d_D, double *d_E,
                             double *d_TAU, double *d_Q, int64_t ldq, void *d_work, int64_t work_bytes);
 int64_t jcdf_sytrd_max_n(int32_t with_q);
+/* The tridiagonalisation kernels are PERSISTENT: their G <= 256 workgroups hand columns to each other and must all be resident
+ * at once.  Before every such launch the library checks hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs >= G for the
+ * kernel at its block size and LDS (JCDF_ERR_INVALID otherwise: refused, not discovered by a spin timeout).  The launch
+ * itself: mode 2 = always hipLaunchCooperativeKernel; mode 1 (default) = cooperative when G exceeds half the CUs — two such
+ * kernels (another stream, another rank on the card) could not be resident together and must queue up rather than each
+ * hold part of the chip — and a plain launch for the smaller grids that fit side by side (the cooperative launch costs
+ * ~50 us per eigensolve); mode 0 = never cooperative.  The bounded spins inside the kernels (50 ms, error word of
+ * jcdf_sytrd_workspace_bytes) stay as the second line.  Process-wide. */
+int32_t jcdf_set_persistent_launch_mode(int32_t mode);
 /* Back-transformation of the same eigensolve for the sizes above jcdf_sytrd_max_n(1), where Q is not accumulated in the
  * tridiagonalisation (LAPACK dormtr('L','L','N') semantics, the third stage of dsyevd behind SCF.jl:1083): C <- Q C with
  * Q = H_0 H_1 ... from the reflectors and d_TAU that jcdf_sytrd_device left in d_A, by blocked compact-WY on the library's

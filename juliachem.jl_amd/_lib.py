@@ -76,6 +76,7 @@ PROTOTYPES = {
     "jcdf_sytrd_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
     "jcdf_sytrd_q_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64]),
     "jcdf_sytrd_max_n": (_I64, [C.c_int32]),
+    "jcdf_set_persistent_launch_mode": (C.c_int32, [C.c_int32]),
     "jcdf_ormtr_workspace_bytes": (_I64, [_I64]),
     "jcdf_ormtr_device": (C.c_int32, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64]),
     "jcdf_diis_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),

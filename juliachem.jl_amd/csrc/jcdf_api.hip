@@ -26,6 +26,7 @@
 #include <new>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -79,7 +80,7 @@ struct jcdf_handle {
     bool configured = false, have_metric = false, have_B = false, have_H = false, pushed_any = false;
     bool dense_map = true;
     // jcdf_set_tuning (persist across jcdf_configure); 0 = the library's own rule
-    int64_t tune_k_slices_per_xcd = 0, tune_w_chunk_stages = 0, tune_host_cholesky = 0;
+    int64_t tune_k_slices_per_xcd = 0, tune_w_chunk_stages = 0, tune_host_cholesky = 0, tune_j_workgroups = 0, tune_k_first = 0;
 
     // device buffers
     double *dB = nullptr, *dCpad = nullptr, *dCv = nullptr, *dWt = nullptr, *dVpart = nullptr, *dV = nullptr;
@@ -352,6 +353,13 @@ bool fold_set(jcdf_handle *h, int set, bool wait)
     return true;
 }
 
+// J beside K (side stream) or one after the other: the handle's switch; diagnostic builds: JCDF_OVERLAP_JK overrides
+bool overlap_env_now(const jcdf_handle *h)
+{
+    static const int overlap_env = [] { const char *e = diag_env("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
+    return overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk;
+}
+
 int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, int64_t ldf, hipStream_t st)
 {
     // the set this build records into held the build before last: its times are read now at the latest (a build that is
@@ -393,10 +401,23 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, 
                            (int)h->Ql, (int)h->ldq, h->dV);
     };
     // e0 / e1: indices of the events that bracket the launch; the caller records them
+    const bool overlapped = overlap_env_now(h);
     auto run_J = [&](size_t slot, hipStream_t st, int e0, int e1) {
         KernelRec &r = rec_slot(h, slot, "k_coulomb_J", e0, e1);
         const int64_t groups = (h->Plow + 4 * J_ROWS - 1) / (4 * J_ROWS);
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, (int64_t)h->num_cu * JCDF_J_BLOCKS_PER_CU));
+        int64_t cap = (int64_t)h->num_cu * JCDF_J_BLOCKS_PER_CU;
+        if (overlapped) {
+            // Beside K there is room for ONE workgroup of this kernel per CU (K: two workgroups of four 216-VGPR waves, 128 KB of
+            // LDS).  A grid of exactly that many workgroups is resident from start to end and evenly loaded; a larger grid leaves
+            // a tail of workgroups that start when the first ones finish (256: window 0.76 ms, 288: 0.94, 1536: 0.82-0.87;
+            // profiles/r04_jk_phase.txt).  Only while K is the longer of the two: a J pass that outlasts K (few occupied
+            // orbitals) keeps the full grid and fills the chip once K is gone.
+            const double k_est = 2.0 * (double)h->nblk64 * 64.0 * 64.0 * (double)h->S * (double)h->KS / 55.0e12;
+            const double j_est = 8.0 * Ql * (double)h->Plow / 2.5e12;              // at the rate it reaches beside K
+            if (k_est >= j_est) cap = h->num_cu;
+            if (h->tune_j_workgroups > 0) cap = h->tune_j_workgroups;
+        }
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, cap));
         hipLaunchKernelGGL(k_coulomb_J, dim3(grid), dim3(256), (size_t)h->ldq * sizeof(double), st, h->dB, h->ldq, h->dV,
                            h->dJrow, h->Plow, h->dJ);
         r.flops = r.alg_flops = 2.0 * Ql * (double)h->Plow;
@@ -414,18 +435,24 @@ int32_t enqueue_fock(jcdf_handle *h, const double *dC, int64_t ldc, double *dF, 
     };
     // record slots stay fixed (2 = J, 3 = K) whatever the launch order
     static const bool k_first = [] { const char *e = diag_env("JCDF_K_BEFORE_J"); return e && atoi(e) != 0; }();
-    static const int overlap_env = [] { const char *e = diag_env("JCDF_OVERLAP_JK"); return e ? atoi(e) : -1; }();
     run_reduce_V(st);                                  // 13 us alone, 36 us when it has to start beside the K kernel's workgroups
     ok(hipEventRecord(E[3], st));
-    if (overlap_env >= 0 ? overlap_env != 0 : h->overlap_jk) {
+    if (overlapped) {
         // J (streams half of B, no MFMA) on a side stream while K (MFMA, W out of L2) runs: both only need W's outputs.
         // The fork and the join are the timing events themselves.
         if (!h->side) ok(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         ok(hipStreamWaitEvent(h->side, E[3], 0));
-        run_J(2, h->side, 3, 4);
-        ok(hipEventRecord(E[4], h->side));
-        run_K(3, 3, 5);
-        ok(hipEventRecord(E[5], st));
+        if (!h->tune_k_first) {                            // default: J's latency ramp in front of K's first stage
+            run_J(2, h->side, 3, 4);
+            ok(hipEventRecord(E[4], h->side));
+            run_K(3, 3, 5);
+            ok(hipEventRecord(E[5], st));
+        } else {
+            run_K(3, 3, 5);
+            ok(hipEventRecord(E[5], st));
+            run_J(2, h->side, 3, 4);
+            ok(hipEventRecord(E[4], h->side));
+        }
         ok(hipStreamWaitEvent(st, E[4], 0));
     } else if (k_first) {
         run_K(3, 3, 5);
@@ -781,6 +808,67 @@ hipError_t ensure_device_attributes()
 
 }  // namespace
 
+// ---- launch of a PERSISTENT kernel (every workgroup spins on hand-offs from its peers: all G must be co-resident) ----------
+// First line: the capacity is checked, not assumed — hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs >= G for this kernel
+// with this block size and LDS (cached per device / kernel / shape) — and the launch goes through
+// hipLaunchCooperativeKernel, the runtime's own co-residency contract (mode 2: always; mode 1, the default: when the grid is
+// larger than half the chip), or a plain launch after the same check (mode 0).  Second line: the bounded spins inside the
+// kernels (50 ms, error word).
+static int g_persistent_mode = 1;
+namespace {
+struct OccKey {
+    int dev; const void *fn; int threads; size_t lds;
+    bool operator<(const OccKey &o) const { return std::tie(dev, fn, threads, lds) < std::tie(o.dev, o.fn, o.threads, o.lds); }
+};
+std::mutex g_occ_mutex;
+std::map<OccKey, int> g_occ_cache;          // -> co-resident workgroups on the whole device
+std::map<int, int> g_coop_ok;               // device -> hipDeviceAttributeCooperativeLaunch
+
+template <class... KArgs, class... Args>
+int32_t launch_persistent(void (*kernel)(KArgs...), int G, int threads, size_t lds, hipStream_t st, Args... args)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return JCDF_ERR_HIP;
+    int capacity = 0, coop = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_occ_mutex);
+        const OccKey key{dev, (const void *)kernel, threads, lds};
+        auto it = g_occ_cache.find(key);
+        if (it == g_occ_cache.end()) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, threads, lds) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                return JCDF_ERR_HIP;
+            it = g_occ_cache.emplace(key, per_cu * cus).first;
+        }
+        capacity = it->second;
+        auto ic = g_coop_ok.find(dev);
+        if (ic == g_coop_ok.end()) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) v = 0;
+            ic = g_coop_ok.emplace(dev, v).first;
+        }
+        coop = ic->second;
+    }
+    if (capacity < G) return JCDF_ERR_INVALID;               // the grid can never be co-resident on this device: refuse, do not spin
+    std::tuple<KArgs...> held(args...);                       // exact parameter types, addressable
+    // mode 1: cooperative where two such kernels (another stream, another rank on the same card) could NOT be resident together —
+    // G above half the CUs — so that they queue up behind each other instead of each holding part of the chip and spinning;
+    // smaller grids fit side by side and keep the plain launch (the cooperative one costs ~50 us per eigensolve, measured)
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (coop && (g_persistent_mode == 2 || (g_persistent_mode == 1 && 2 * G > cus))) {
+        void *argv[sizeof...(KArgs)];
+        size_t i = 0;
+        std::apply([&](auto &...a) { ((argv[i++] = (void *)&a), ...); }, held);
+        return hipLaunchCooperativeKernel((const void *)kernel, dim3((unsigned)G), dim3((unsigned)threads), argv, (unsigned)lds, st) == hipSuccess
+                   ? JCDF_OK : JCDF_ERR_HIP;
+    }
+    std::apply([&](auto &...a) { hipLaunchKernelGGL(kernel, dim3((unsigned)G), dim3((unsigned)threads), lds, st, a...); }, held);
+    return JCDF_OK;
+}
+}  // namespace
+
 // ============================================================================
 extern "C" {
 
@@ -877,6 +965,11 @@ int32_t jcdf_set_tuning(jcdf_handle *h, const char *key, int64_t value)
         h->tune_w_chunk_stages = value;
     } else if (k == "host_cholesky") {
         h->tune_host_cholesky = value != 0;
+    } else if (k == "j_workgroups") {
+        if (value > 1 << 16) return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: j_workgroups too large");
+        h->tune_j_workgroups = value;
+    } else if (k == "k_first") {
+        h->tune_k_first = value != 0;
     } else {
         return fail(h, JCDF_ERR_INVALID, "jcdf_set_tuning: unknown key '" + k + "'");
     }
@@ -1455,6 +1548,13 @@ int32_t jcdf_host_potrf_trtri(double *A, int64_t n)
     return hostlapack::potrf_trtri_lower(A, n);
 }
 
+int32_t jcdf_set_persistent_launch_mode(int32_t mode)
+{
+    if (mode < 0 || mode > 2) return JCDF_ERR_INVALID;
+    g_persistent_mode = mode;
+    return JCDF_OK;
+}
+
 // ---- replicated eigensolve helper (caller side) ----------------------------
 static size_t sytrd_lds(int64_t n, int G, bool with_q)
 {
@@ -1548,8 +1648,9 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
     do {                                                                                                                    \
         if (hipFuncSetAttribute((const void *)k_sytrd_onehop<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) \
             return JCDF_ERR_HIP;                                                                                            \
-        hipLaunchKernelGGL(k_sytrd_onehop<NR>, dim3((unsigned)G1), dim3(512), lds1, st, d_A, (int)lda, (int)n, d_D, d_E,    \
-                           d_TAU, vg, yg, hg, err, d_Q, (int)ldq, kstop);                                                   \
+        const int32_t rc_ = launch_persistent(k_sytrd_onehop<NR>, G1, 512, lds1, st, d_A, (int)lda, (int)n, d_D, d_E,       \
+                                              d_TAU, vg, yg, hg, err, d_Q, (int)ldq, kstop);                                \
+        if (rc_) return rc_;                                                                                                \
     } while (0)
         if (n <= 64) JCDF_ONEHOP(2);
         else if (n <= 256) JCDF_ONEHOP(8);
@@ -1569,8 +1670,9 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         // with every update applied — a symmetric matrix of the size the one-exchange kernel holds (5.7 us per column), which
         // continues on it in place, followed by the one-workgroup tail: n = 1915 13.5 -> 10.6 ms (profiles/r04_eigh_stages.txt).
         const int64_t k1 = n - SYTRD_ONEHOP_MAX_N, n2 = SYTRD_ONEHOP_MAX_N;
-        hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(512), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg, hg, err,
-                           (double *)nullptr, 0, (int)k1);
+        if (int32_t rc1 = launch_persistent(k_sytrd_lower, G, 512, lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg, hg, err,
+                                            (double *)nullptr, 0, (int)k1))
+            return rc1;
         // fresh granules for the second kernel (tags restart at 1); the error word in the header stays as the first kernel left it
         if (hipMemsetAsync(w + 64, 0, (size_t)sytrd_granule_bytes(n) - 64, st) != hipSuccess) return JCDF_ERR_HIP;
         const int G2 = (int)((n2 + 7) / 8);
@@ -1578,13 +1680,15 @@ int32_t jcdf_sytrd_q_device(void *stream, int64_t n, double *d_A, int64_t lda, d
         if (hipFuncSetAttribute((const void *)k_sytrd_onehop<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return JCDF_ERR_HIP;
         double *A2 = d_A + k1 * (lda + 1);
         jcdf::u64 *vg2 = (jcdf::u64 *)(w + 64), *yg2 = vg2 + 2 * (n2 + 2), *hg2 = yg2 + 2 * ((n2 + 1) & ~(int64_t)1);
-        hipLaunchKernelGGL(k_sytrd_onehop<48>, dim3((unsigned)G2), dim3(512), lds2, st, A2, (int)lda, (int)n2, d_D + k1, d_E + k1, d_TAU + k1,
-                           vg2, yg2, hg2, err, (double *)nullptr, 0, tail ? (int)(n2 - SYTD2_TAIL_T) : (int)n2);
+        if (int32_t rc2 = launch_persistent(k_sytrd_onehop<48>, G2, 512, lds2, st, A2, (int)lda, (int)n2, d_D + k1, d_E + k1, d_TAU + k1,
+                                            vg2, yg2, hg2, err, (double *)nullptr, 0, tail ? (int)(n2 - SYTD2_TAIL_T) : (int)n2))
+            return rc2;
         return finish();
     }
     // 512 threads from n = 1000 on: half the dependent polls and half the elements per thread (n = 1250: 9.04 -> 8.69 ms; n = 700: equal)
-    hipLaunchKernelGGL(k_sytrd_lower, dim3((unsigned)G), dim3(n >= 1000 ? 512 : 256), lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
-                       hg, err, d_Q, (int)ldq, kstop);
+    if (int32_t rc3 = launch_persistent(k_sytrd_lower, G, n >= 1000 ? 512 : 256, lds, st, d_A, (int)lda, (int)n, d_D, d_E, d_TAU, vg, yg,
+                                        hg, err, d_Q, (int)ldq, kstop))
+        return rc3;
     return finish();
 }
 

@@ -413,11 +413,18 @@ constexpr int J_UNROLL = JCDF_J_UNROLL;
 #ifndef JCDF_J_BLOCKS_PER_CU
 #define JCDF_J_BLOCKS_PER_CU 6
 #endif
+#ifndef JCDF_J_PRIO
+#define JCDF_J_PRIO 3
+#endif
 __global__ __launch_bounds__(256, JCDF_J_BLOCKS_PER_CU) void k_coulomb_J(
     const double *__restrict__ Bp, int64_t ldq, const double *__restrict__ V, const int *__restrict__ jrow,
     int64_t nrows, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double Vs[];
+    // Beside the K kernel (two 216-VGPR MFMA waves per SIMD) this kernel's one wave per SIMD was starved of issue slots at the
+    // default priority: 53 % of its bytes in the 0.72 ms K needs, the rest behind it (window 0.87 ms).  At priority 3 it
+    // streams while K multiplies and both end together: window 0.76 ms, K itself 0.72 -> 0.75 (profiles/r04_jk_phase.txt).
+    __builtin_amdgcn_s_setprio(JCDF_J_PRIO);
     for (int k = threadIdx.x; k < (int)ldq; k += blockDim.x) Vs[k] = V[k];
     __syncthreads();
     const int lane = threadIdx.x & 63;

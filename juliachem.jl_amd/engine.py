@@ -570,18 +570,23 @@ class DeviceSCF:
             # trouble flags are OR-ed over the ranks, everything else is rank 0's record — ONE small all-reduce (sum): the
             # other ranks contribute zeros to the record part, every rank its own flags
             rec, dist = self.tail_out, self.fb.dist
-            buf = torch.zeros(10, dtype=torch.float64, device=rec.device)
+            buf = torch.zeros(11, dtype=torch.float64, device=rec.device)
             if self.fb.rank == 0:
                 buf[:8] = rec
             buf[8] = (rec[3] != 0).to(torch.float64)
             if use_sp2:
-                good = (rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & (rec[6] >= 1.0) & torch.isfinite(rec[0])
-                buf[9] = (~good).to(torch.float64)
+                # two separate flags: trouble with the PROJECTOR (squarings not finished / trace off / not finite)
+                # and trouble with the BASIS only (Newton-Schulz steps too few) — the second has its own, cheaper retry in
+                # step(), which every rank must enter together, and must not double the squarings enqueued next time
+                proj_bad = ~((rec[4] == 1.0) & ((rec[5] - self.n_occ).abs() < 1e-6) & torch.isfinite(rec[0]))
+                buf[9] = proj_bad.to(torch.float64)
+                buf[10] = (~(rec[6] >= 1.0)).to(torch.float64)
             _all_reduce(dist, buf)
             rec.copy_(buf[:8])
             rec[3] = buf[8]
             if use_sp2:
-                rec[4] = torch.where(buf[9] != 0, torch.zeros_like(rec[4]), rec[4])
+                rec[4] = torch.where(buf[9] != 0, torch.zeros_like(rec[4]), rec[4])     # some rank's projector failed: unfinished everywhere
+                rec[6] = torch.where(buf[10] != 0, torch.zeros_like(rec[6]), rec[6])    # some rank's basis failed: retried everywhere
         return self.tail_out.cpu().tolist()
 
     def canonical_orbitals(self) -> None:

@@ -462,6 +462,53 @@ def test_device_eigh_reports_non_finite_input_and_sizes_outside_its_kernels():
     assert not big.ok and "limit" in big.reason
 
 
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_device_eigh_beside_a_co_tenant_that_holds_the_cus(mode):
+    """the persistent tridiagonalisation kernel needs all its workgroups resident at once.  The launch
+    checks the capacity (occupancy x CUs >= G) and goes through hipLaunchCooperativeKernel (mode 2: always; mode 1, default:
+    for grids above half the chip; mode 0: plain launch after the same check).  Here a co-tenant — a queue of large fp64 GEMMs on another stream, every CU busy for
+    ~0.2 s — is running when the eigensolver is enqueued: correct result, no hand-off timeout, no vendor fallback."""
+    import torch
+    from juliachem_jl_amd import _lib
+    from juliachem_jl_amd.eigh import DeviceEigh
+    lib = _lib.load()
+    assert lib.jcdf_set_persistent_launch_mode(7) == 1            # JCDF_ERR_INVALID
+    assert lib.jcdf_set_persistent_launch_mode(mode) == 0
+    try:
+        dev = torch.device("cuda", 0)
+        n = 510
+        rng = np.random.default_rng(77)
+        A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T)
+        dA = torch.as_tensor(A, device=dev)
+        eg = DeviceEigh(n, dev)
+        eg(dA)                                                      # warm (attributes, plans)
+        torch.cuda.synchronize()
+        big = torch.randn((6144, 6144), dtype=torch.float64, device=dev)
+        out = torch.empty_like(big)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                torch.mm(big, big, out=out)                         # ~8 ms each: every CU, most of its LDS
+            done.record(side)
+        results = []
+        for _ in range(6):                                          # enqueued while the co-tenant runs
+            w, U = eg(dA)
+            results.append((w.clone(), U.clone()))
+        overlapped = not done.query()                               # the co-tenant was still busy when the last solve was enqueued
+        torch.cuda.synchronize()
+        assert eg.check() and eg.fallbacks == 0 and eg.ok, getattr(eg, "reason", "")
+        wref = np.linalg.eigvalsh(A)
+        for w, U in results:
+            w = w.cpu().numpy(); U = U.cpu().numpy()
+            assert np.abs(w - wref).max() < 1e-12 * n * np.abs(wref).max()
+            assert np.abs(A @ U - U * w[None, :]).max() < 1e-12 * n * np.abs(wref).max()
+        assert overlapped
+    finally:
+        lib.jcdf_set_persistent_launch_mode(1)
+
+
 @pytest.mark.parametrize("n", [31, 47, 128, 129, 200, 300])
 def test_device_eigh_graded_matrix(n):
     """Graded matrices (a core Hamiltonian in the orthonormal basis: diagonal from -30 down to 1e-3) through every split of the
