@@ -67,8 +67,8 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-PMC_RECORD = os.path.join("profiles", "r03_pmc_traffic.json")
-STEP_RECORD = os.path.join("profiles", "r03_step_kernels.json")
+PMC_RECORD = os.path.join("profiles", "r04_pmc_traffic.json")
+STEP_RECORD = os.path.join("profiles", "r04_step_kernels.json")
 
 
 def checked_record(rel, shape=None):

@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
 # Run on the GPU box (via gpurun): kernel-trace stats + PMC passes of the bench / Fock build and the per-step kernel record;
-# summaries land in gpurun_out/<tag>/ and are copied into profiles/<tag>_* by the developer (tools/collect_round_profiles.sh r03
-# && cp gpurun_out/r03/{kernel_stats_*.txt,pmc_traffic.json,pmc_summary.txt,step_kernels.json,step_timeline_eigh.txt} profiles/).
+# summaries land in gpurun_out/<tag>/ and are copied into profiles/<tag>_* by the developer (tools/collect_round_profiles.sh r04
+# && cp gpurun_out/r04/{kernel_stats_*.txt,pmc_traffic.json,pmc_summary.txt,step_kernels.json,step_timeline_eigh.txt} profiles/).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
@@ -67,7 +67,7 @@ for f in glob.glob(out + "/pmc/*/*/*counter_collection.csv") + glob.glob(out + "
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "jcdf::" in k: agg[k.replace("jcdf::", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # the record is only valid for the kernel sources and the shape it was measured on: bench.py checks both
-tr = {"csrc_sha256_16": bench.csrc_hash(), "shape": [510, 1950, 81], "command": "tools/pmc_passes.sh (tools/prof_fock.py C20H42 3)"}
+tr = {"csrc_sha256_16": bench.csrc_hash(), "shape": [510, 1950, 81], "command": "tools/pmc_passes.sh (tools/prof_fock.py C20H42 3, JCDF_PROF_NO_OVERLAP=1: J after K, every kernel alone)"}
 for k, c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:

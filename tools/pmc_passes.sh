@@ -4,6 +4,7 @@
 set -u
 OUT=${1:-gpurun_out/pmc}; CFG=${2:-C20H42}
 export TMPDIR=/tmp
+export JCDF_PROF_NO_OVERLAP=1      # J one after K (not beside it on the side stream): the cycle counters of a launch belong to that launch
 mkdir -p "$OUT"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 tools/prof_fock.py "$CFG" 3 > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAIT_INST_LDS

@@ -38,6 +38,8 @@ for s0 in range(0, Q, step):
     T = T.reshape(N * N, s1 - s0)[sel].contiguous().reshape(-1) if kept is not None else T.reshape(-1)
     fb.push_three_center_device(s0, s1, T)
 torch.cuda.synchronize()
+if os.environ.get("JCDF_PROF_NO_OVERLAP") == "1":        # PMC passes: every kernel alone on the device, so its counters are its own
+    fb.h.set_overlap(False)
 C, _ = np.linalg.qr(rng.standard_normal((N, N)))
 Ct = torch.as_tensor(np.ascontiguousarray(C[:, :o].T), device=dev)
 for _ in range(nb):
