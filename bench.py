@@ -228,7 +228,7 @@ def max_over_ranks(x, world, dev):
     return float(tt.item())
 
 
-def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=None):
+def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=None, config="w50", steps_cap=10):
     """BASELINE config 4: the (H2O)50 / cc-pVDZ shape (1250 / 4800 / 250), aux index sharded over the ranks, one F
     all-reduce per iteration.  kept = None: unscreened map (60 GB of B in all); kept = 0.13: a scattered 3-D-cluster map
     with the kept fraction of the real cluster (profiles/r02_w50_real_run.txt) — what the reference's adaptive rule runs
@@ -238,7 +238,7 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     import juliachem_jl_amd as jc
     from juliachem_jl_amd import synthetic
     from juliachem_jl_amd.engine import DeviceSCF
-    N, Q, o = synthetic.CONFIGS["w50"]
+    N, Q, o = synthetic.CONFIGS[config]
     rng = np.random.default_rng(synthetic.SEED + 50)
     pq = (None, None)
     if kept is None:
@@ -271,13 +271,24 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     scf = DeviceSCF(fb, H, np.eye(N), 0.0, density_solver=density_solver or args.density_solver)
     torch.cuda.synchronize(dev)
     t_setup = time.perf_counter() - t_setup
-    steps = max(3, min(args.steps, 10))
+    steps = max(3, min(args.steps, steps_cap))
     elapsed, kstats, fock_ms, coll_ms = run_scf_steps(scf, fb, steps, 8 if density_solver == "sp2" else 2, barrier)
     elapsed = max_over_ranks(elapsed, world, dev)
     nbytes = fb.h.device_bytes()
     rep = scf.solver_report()
     ms = elapsed / steps * 1e3
     Ql = R
+    eig_ms = None
+    if scf.density_solver == "eigh" and scf.eigh.ok:            # outside the timed steps: the stages of the replicated eigensolve
+        scf.eigh.timing = True
+        for _ in range(2):
+            scf.step()
+        torch.cuda.synchronize(dev)
+        a_ms, b_ms = scf.eigh.stage_ms()
+        scf.eigh.timing = False
+        eig_ms = {"tridiagonalisation_ms": a_ms, "tridiagonal_solver_ms": b_ms,
+                  "back_transformation": "one GEMM with the Q accumulated in the kernel" if scf.eigh.with_q else
+                  "blocked compact-WY from the stored reflectors (jcdf_ormtr_device)"}
     n_shards = len(fb.ranges)
     if args.in_process:
         # member 0's events cover its shard only: the build of the whole group (fetch of C, longest member, reduce, gather) is
@@ -292,7 +303,7 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
            "kept_pair_fraction": P / float(N * N), "aux_rows_rank0": Ql, "device_GB_rank0": nbytes / 1e9,
            "fock_build_useful_tflops": fock_useful_flops(N, Q, o, P) / (fock_ms * 1e-3) / 1e12,
            "fock_build_tflops_dense_formula": fock_alg_flops(N, Q, o) / (fock_ms * 1e-3) / 1e12,
-           "setup_s": t_setup, "eigensolver": rep, "density_solver": scf.density_solver,
+           "setup_s": t_setup, "eigensolver": rep, "eigensolver_stages": eig_ms, "density_solver": scf.density_solver,
            "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries}
     if args.in_process:
         out["group"] = dict(gtm, transport=fb.g.transport())
@@ -420,6 +431,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="C20H42")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-w50", action="store_true", help="skip the scaling_w50 object")
+    ap.add_argument("--no-gly10", action="store_true", help="skip the gly10_vtz object (BASELINE config 5 shape, 30 %-kept map)")
     ap.add_argument("--no-real", action="store_true", help="skip the real_molecule object (profiling runs)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host_boundary object (host C in, host F out through the C ABI)")
     ap.add_argument("--in-process", action="store_true",
@@ -646,6 +658,17 @@ def main(argv=None):
                # iteration): what the replicated part costs strong scaling — informational, like `alt`
                "screened_13pct_sp2": measure_w50(args, world, rank, local, dev, barrier, 0.13, density_solver="sp2")}
 
+    # BASELINE config 5: the glycine-oligomer / cc-pVTZ shape (N = 1915: above the size whose Q fits the tridiagonalisation
+    # kernel — two-kernel tridiagonalisation + compact-WY back-transformation, no vendor kernel), 30 %-kept map; never `value`
+    gly10 = None
+    if not args.no_gly10 and not args.no_w50:
+        gly10 = measure_w50(args, world, rank, local, dev, barrier, 0.30, config="gly10_vtz", steps_cap=4)
+        gly10["workload"] = "glycine-oligomer / cc-pVTZ shaped DF-RHF SCF iteration (BASELINE config 5): N=1915 AO, Q=5261 aux, n_occ=155, 30 %-kept pair map"
+        rec5, why5 = checked_record(os.path.join("profiles", "r04_step_kernels_gly10.json"), (1915, 5261, 155)) if n_shards == 1 else (None, "single-GPU record")
+        gly10["vendor_kernels_per_step"] = rec5.get("vendor_kernels_per_step") if rec5 else None
+        gly10["step_kernels_source"] = ("profiles/r04_step_kernels_gly10.json (rocprofv3 --kernel-trace of tools/scf_steps.py gly10_vtz; csrc hash checked)"
+                                        if rec5 else why5)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         P = N * N
@@ -729,6 +752,7 @@ def main(argv=None):
                                         "note": "stand-alone launch after the timed loop; in the timed steps J overlaps K (kernels_ms)"}},
             "longest_kernel": longest,
             "scaling_w50": w50,
+            "gly10_vtz": gly10,
         }
         if n_shards == 1 and not args.no_real:
             out["real_molecule"] = real_molecule()

@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -o a -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-w50 --no-real > "$OUT/trace_bench.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_fock" -o a -- python3 tools/prof_fock.py C20H42 10 > "$OUT/trace_fock.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gly10" -o a -- python3 tools/scf_steps.py gly10_vtz 0.30 5 > "$OUT/trace_gly10.log" 2>&1
 tools/pmc_passes.sh "$OUT/pmc" C20H42 > "$OUT/pmc.log" 2>&1
 cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
 python3 - "$OUT" "$TAG" <<'PY'
@@ -60,6 +61,24 @@ json.dump({"csrc_sha256_16": bench.csrc_hash(), "shape": [510, 1950, 81], "comma
            "vendor_kernels_per_step": fam["vendor"], "small_launch_ms_per_step": small_ms,
            "small_launch_note": "everything outside W / K / J / reduce_V / prep_C / assemble / sytrd (+ tail) / D&C",
            "kernels": [r["Kernel_Name"].split("(")[0].replace("void ", "")[:80] for r in one]}, open(out + "/step_kernels.json", "w"), indent=1)
+# ---- one SCF step of the gly10 shape (BASELINE config 5: N = 1915, above the size whose Q fits the tridiagonalisation kernel) -----
+tg = glob.glob(out + "/trace_gly10/*kernel_trace.csv") + glob.glob(out + "/trace_gly10/*/*kernel_trace.csv")
+if tg:
+    rows5 = sorted(csv.DictReader(open(tg[0])), key=lambda r: int(r["Start_Timestamp"]))
+    idx5 = [i for i, r in enumerate(rows5) if "k_exchange_W" in r["Kernel_Name"]]
+    one5 = rows5[idx5[-2]:idx5[-1]]                      # the second-to-last step, Fock build to Fock build
+    fam5, tot5 = collections.Counter(), collections.Counter()
+    for r in one5:
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        f = "library" if "jcdf::" in n else ("vendor" if re.search(r"rocblas|rocsolver|Cijk_|hipblaslt|Tensile", n) else "torch")
+        fam5[f] += 1
+        tot5[n.split("<")[0]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    step5 = (int(rows5[idx5[-1]]["Start_Timestamp"]) - int(rows5[idx5[-2]]["Start_Timestamp"])) / 1e3
+    json.dump({"csrc_sha256_16": bench.csrc_hash(), "shape": [1915, 5261, 155], "command": "rocprofv3 --kernel-trace -- python3 tools/scf_steps.py gly10_vtz 0.30 5",
+               "step_us": step5, "launches_per_step": sum(fam5.values()), "library_kernels_per_step": fam5["library"], "torch_kernels_per_step": fam5["torch"],
+               "vendor_kernels_per_step": fam5["vendor"], "kernel_us_per_step": dict(sorted(tot5.items(), key=lambda kv: -kv[1])[:24])},
+              open(out + "/step_kernels_gly10.json", "w"), indent=1)
+    print(open(out + "/step_kernels_gly10.json").read()[:1800])
 # ---- PMC per launch (KB counters; FETCH_SIZE x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH HBM section) ----------
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc/*/*/*counter_collection.csv") + glob.glob(out + "/pmc/*/*counter_collection.csv"):
