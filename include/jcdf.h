@@ -303,12 +303,23 @@ int32_t jcdf_lowdin_rows_device(void *stream, int64_t o, int64_t n, const double
  * leading dimension ldf) by trace-correcting second-order spectral projection (csrc/jcdf_sp2.hpp) — matrix
  * squarings on MFMA, no host round trip.  `iterations` squarings are enqueued; those after convergence return at
  * once.  On return (stream-ordered) d_P (n x n, leading dimension ldp) holds the current iterate and d_info
- * (8 doubles, device) = {squarings done, finished (1/0), tr P, last tr(X - X^2), Gershgorin lo, hi, -, -}:
+ * (8 doubles, device) = {squarings done, finished (1/0), tr P, last tr(X - X^2), spectral bounds lo, hi, accelerated (1/0), delta}:
  * the caller accepts P when finished == 1 and |tr P - n_occ| is small, and otherwise calls again with more
  * iterations or takes the eigensolver.  d_work: jcdf_sp2_workspace_bytes(n) bytes of device memory. */
 int64_t jcdf_sp2_workspace_bytes(int64_t n);
 int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_F, int64_t ldf, double *d_P, int64_t ldp,
                         int32_t iterations, void *d_work, int64_t work_bytes, double *d_info);
+/* The same with a REFERENCE decomposition: d_Fref (n x n, leading dimension ldr) is a matrix the caller has diagonalised before
+ * (an earlier SCF iteration) and d_ref_eigs (4 doubles, device) = {lowest, HOMO (n_occ-th), LUMO, highest} of ITS eigenvalues.
+ * With delta = ||d_F - d_Fref||_F (formed on the device) Weyl's inequality bounds the spectrum of d_F by
+ * [lowest - delta, highest + delta] — taken instead of the Gershgorin interval where tighter — and brackets its gap by
+ * HOMO + delta < LUMO - delta; while that bracket is open the accelerated recursion of Rubensson (JCTC 7, 1233) is used (each
+ * step preceded by the affine stretch that folds the far end of the spectrum onto itself; csrc/jcdf_sp2.hpp): about half the
+ * squarings.  The bounds are rigorous, so the result is the same projector; info[6] = 1 when the accelerated recursion ran,
+ * info[7] = delta.  Both NULL: jcdf_sp2_device. */
+int32_t jcdf_sp2_ref_device(void *stream, int64_t n, int64_t n_occ, const double *d_F, int64_t ldf, double *d_P, int64_t ldp,
+                            int32_t iterations, void *d_work, int64_t work_bytes, double *d_info, const double *d_Fref, int64_t ldr,
+                            const double *d_ref_eigs);
 
 
 /* Small dense products of the device-resident SCF iteration on the library's own fp64 MFMA cores (csrc/jcdf_blas.hpp), so

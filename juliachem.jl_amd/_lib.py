@@ -87,6 +87,7 @@ PROTOTYPES = {
     "jcdf_lowdin_rows_device": (C.c_int32, [_P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P, _I64, _P]),
     "jcdf_sp2_workspace_bytes": (_I64, [_I64]),
     "jcdf_sp2_device": (C.c_int32, [_P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P, _I64, _P]),
+    "jcdf_sp2_ref_device": (C.c_int32, [_P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P, _I64, _P, _P, _I64, _P]),
     "jcdf_gemm_tn_device": (C.c_int32, [_P, _I64, _I64, _I64, C.c_double, _P, _I64, _P, _I64, _P, _I64]),
     "jcdf_gemm_nt_device": (C.c_int32, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64]),
     "jcdf_diis_push_device": (C.c_int32, [_P, _I64, _I64, _P, _P, _P, _P]),

@@ -2058,7 +2058,7 @@ Sp2Work sp2_carve(char *base, int64_t n)
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += roundup((int64_t)bytes, 256); return p; };
     w.Xa = (double *)take((size_t)w.np * w.ld * 8);
     w.Xb = (double *)take((size_t)w.np * w.ld * 8);
-    w.part = (double *)take(2 * 1024 * 8);
+    w.part = (double *)take(3 * 1024 * 8);
     w.partials = (double *)take((size_t)2 * 2 * SP2_PART * 8);
     w.state = (Sp2State *)take(2 * sizeof(Sp2State));
     w.bytes = (int64_t)off;
@@ -2075,24 +2075,31 @@ int64_t jcdf_sp2_workspace_bytes(int64_t n)
 int32_t jcdf_sp2_device(void *stream, int64_t n, int64_t n_occ, const double *d_F, int64_t ldf, double *d_P, int64_t ldp,
                         int32_t iterations, void *d_work, int64_t work_bytes, double *d_info)
 {
+    return jcdf_sp2_ref_device(stream, n, n_occ, d_F, ldf, d_P, ldp, iterations, d_work, work_bytes, d_info, nullptr, 0, nullptr);
+}
+
+int32_t jcdf_sp2_ref_device(void *stream, int64_t n, int64_t n_occ, const double *d_F, int64_t ldf, double *d_P, int64_t ldp,
+                            int32_t iterations, void *d_work, int64_t work_bytes, double *d_info, const double *d_Fref, int64_t ldr,
+                            const double *d_ref_eigs)
+{
     if (n < 2 || n > 4096 || n_occ < 1 || n_occ >= n || !d_F || !d_P || ldf < n || ldp < n || iterations < 1 || iterations > 1000 ||
-        !d_work || !d_info)
+        !d_work || !d_info || ((d_Fref != nullptr) != (d_ref_eigs != nullptr)) || (d_Fref && ldr < n))
         return JCDF_ERR_INVALID;
     Sp2Work w = sp2_carve((char *)d_work, n);
     if (work_bytes < w.bytes) return JCDF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)std::min<int64_t>(1024, (n + 3) / 4);
-    hipLaunchKernelGGL(k_sp2_bounds, dim3(nb), dim3(256), 0, st, d_F, ldf, (int)n, w.part);
+    hipLaunchKernelGGL(k_sp2_bounds, dim3(nb), dim3(256), 0, st, d_F, ldf, (int)n, w.part, d_Fref, ldr);
     hipLaunchKernelGGL(k_sp2_init, dim3((unsigned)w.np), dim3(256), 0, st, d_F, ldf, (int)n, (int)w.np, w.part, nb, w.Xa, w.ld, w.state,
-                       w.partials);
+                       w.partials, d_ref_eigs);
     if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
     for (int k = 0; k < iterations; ++k) {
         if (w.tile == 64)
             hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg64>, dim3((unsigned)(8 * ((w.ntri + 7) / 8))), dim3(Sp2Cfg64::NT), Sp2Cfg64::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa,
-                               w.Xb, w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
+                               w.Xb, w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k, (int)n);
         else
             hipLaunchKernelGGL(k_sp2_fused<Sp2Cfg>, dim3((unsigned)(8 * ((w.ntri + 7) / 8))), dim3(Sp2Cfg::NT), Sp2Cfg::SMEM_BYTES, st, w.Xa, w.Xb, w.Xa, w.Xb,
-                               w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k);
+                               w.ld, (int)n_occ, w.chunks, w.partials, (int)w.np, w.ntri, w.state, k, (int)n);
     }
     hipLaunchKernelGGL(k_sp2_finish, dim3((unsigned)std::min<int64_t>(n, 512)), dim3(256), 0, st, w.Xa, w.Xb, w.ld, (int)n, d_P, ldp,
                        w.state, (int)iterations, d_info);

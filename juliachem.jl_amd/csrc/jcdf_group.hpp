@@ -150,6 +150,14 @@ struct jcdf_group {
 
 namespace {
 
+// A group call visits every member's device; the caller's current device (PyTorch and Julia keep their own idea of it) is put
+// back on every way out.
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -424,6 +432,7 @@ const char *jcdf_group_transport(const jcdf_group *g)
 
 int32_t jcdf_group_destroy(jcdf_group *g)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_OK;
     for (auto h : g->m)
         if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
@@ -445,6 +454,7 @@ int32_t jcdf_group_destroy(jcdf_group *g)
 
 int32_t jcdf_group_create(jcdf_group **out, int32_t n_devices, const int32_t *device_ids)
 {
+    DeviceRestore restore_device_;
     if (!out) { g_group_create_error = "jcdf_group_create: out == NULL"; return JCDF_ERR_INVALID; }
     *out = nullptr;
     if (n_devices < 1 || n_devices > JCDF_GROUP_MAX_DEVICES || !device_ids) {
@@ -491,6 +501,7 @@ int32_t jcdf_group_create(jcdf_group **out, int32_t n_devices, const int32_t *de
 
 int32_t jcdf_group_set_transport(jcdf_group *g, const char *name)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     if (!name) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_set_transport: NULL name");
     const std::string s(name);
@@ -507,6 +518,7 @@ int32_t jcdf_group_set_transport(jcdf_group *g, const char *name)
 
 int32_t jcdf_group_set_exchange_screening(jcdf_group *g, int64_t n_blocks)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     for (int i = 0; i < g->n; ++i) {
         const int32_t rc = gmember(g, i, jcdf_set_exchange_screening(g->m[(size_t)i], n_blocks), "jcdf_set_exchange_screening");
@@ -518,6 +530,7 @@ int32_t jcdf_group_set_exchange_screening(jcdf_group *g, int64_t n_blocks)
 int32_t jcdf_group_configure(jcdf_group *g, int64_t N, int64_t Q_total, const int64_t *shard_q0, int64_t n_occ, int64_t P,
                              const int64_t *pq_p, const int64_t *pq_q)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     if (!shard_q0 || N <= 0) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_configure: NULL shard list / N <= 0");
     if (shard_q0[0] < 0 || shard_q0[g->n] > Q_total) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_configure: shard list outside [0, Q_total]");
@@ -549,6 +562,7 @@ int32_t jcdf_group_configure(jcdf_group *g, int64_t N, int64_t Q_total, const in
 
 int32_t jcdf_group_set_metric(jcdf_group *g, const double *J2c)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     if (!g->configured || !J2c) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_set_metric: configure first / NULL");
     jcdf_handle *h0 = g->m[0];
@@ -590,6 +604,7 @@ int32_t jcdf_group_set_metric(jcdf_group *g, const double *J2c)
 
 int32_t jcdf_group_push_three_center(jcdf_group *g, int64_t s0, int64_t s1, const double *T)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     if (!g->configured) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_push_three_center: configure first");
     jcdf_handle *h0 = g->m[0];
@@ -635,6 +650,7 @@ int32_t jcdf_group_push_three_center(jcdf_group *g, int64_t s0, int64_t s1, cons
 
 int32_t jcdf_group_set_core_hamiltonian(jcdf_group *g, const double *H)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     if (!g->configured) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_set_core_hamiltonian: configure first");
     for (int i = 0; i < g->n; ++i) {
@@ -646,6 +662,7 @@ int32_t jcdf_group_set_core_hamiltonian(jcdf_group *g, const double *H)
 
 int32_t jcdf_group_synchronize(jcdf_group *g, jcdf_timings *t, jcdf_group_timings *gt)
 {
+    DeviceRestore restore_device_;
     if (!g) return JCDF_ERR_INVALID;
     for (int i = 0; i < g->n; ++i) {
         jcdf_handle *h = g->m[(size_t)i];
@@ -667,6 +684,7 @@ int32_t jcdf_group_synchronize(jcdf_group *g, jcdf_timings *t, jcdf_group_timing
 
 int32_t jcdf_group_fock_build(jcdf_group *g, const double *C_occ, double *F_out, jcdf_timings *t, jcdf_group_timings *gt)
 {
+    DeviceRestore restore_device_;
     int32_t rc = group_check_ready(g, "jcdf_group_fock_build");
     if (rc) return rc;
     if (!C_occ || !F_out) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_fock_build: NULL pointer");
@@ -701,6 +719,7 @@ int32_t jcdf_group_fock_build(jcdf_group *g, const double *C_occ, double *F_out,
 
 int32_t jcdf_group_fock_build_device_ld(jcdf_group *g, const double *d_C_occ, int64_t ldc, double *d_F, int64_t ldf, void *stream)
 {
+    DeviceRestore restore_device_;
     int32_t rc = group_check_ready(g, "jcdf_group_fock_build_device_ld");
     if (rc) return rc;
     if (!d_C_occ || !d_F || ldc < g->N || ldf < g->N) return gfail(g, JCDF_ERR_INVALID, "jcdf_group_fock_build_device_ld: NULL pointer / leading dimension < N");

@@ -10,6 +10,20 @@
 // About 30-60 squarings of an N x N matrix: MFMA work on all CUs instead of the N dependent hand-offs of a
 // tridiagonalisation.  Optional path (scf flag density_solver = "sp2"); the eigensolver stays the default.
 //
+// Round 4: bounds from a REFERENCE decomposition and the accelerated recursion (Rubensson, JCTC 7, 1233 (2011)).  The caller
+// may hand over a matrix F_ref it has diagonalised before (an earlier SCF iteration) with four of its eigenvalues
+// {min, HOMO, LUMO, max}.  With delta = ||F' - F_ref||_F every eigenvalue of F' lies within delta of the corresponding one of
+// F_ref (Weyl), so  [min - delta, max + delta]  bounds the spectrum (intersected with the Gershgorin interval; a dense matrix
+// has Gershgorin radii ~14 x its spectral radius: 52 -> 37 squarings at N = 510 from the bounds alone), and
+// HOMO + delta < LUMO - delta brackets the gap: with rigorous bounds h <= (mapped HOMO) and l >= (mapped LUMO) each step is
+// preceded by the affine stretch that folds the far end of the spectrum onto itself,
+//     X^2        ->  (a X + (1 - a) I)^2,  a = 2 / (2 - l)      (virtual range [0, l] -> [-l/(2-l), l/(2-l)] before the squaring)
+//     2 X - X^2  ->  2 (a X) - (a X)^2,    a = 2 / (1 + h)      (occupied range [h, 1] -> symmetric about 1)
+// and h, l are carried through the same polynomials.  Both are combinations c2 X^2 + c1 X + c0 I of the product the launch
+// computes anyway: the epilogue changes, nothing else.  37 -> 21-27 squarings at N = 510, 47 -> 24-30 at N = 1250 (numpy
+// model, gap under-estimated up to 10 x); bounds that are not rigorous can only cost convergence within the squarings
+// enqueued, which the caller detects as before (finished = 0 -> more squarings or the eigensolver).
+//
 // Device program: k_sp2_bounds, k_sp2_init once, then ONE launch per squaring (k_sp2_fused): X is symmetric, so
 // X^2 = X^T X is the k-major SYRK of the K kernel — lower block-triangle of 32 x 32 tiles on the TN MFMA core, each
 // workgroup over the whole contraction length, the update as its epilogue.  tr X^2 = ||X||_F^2 for symmetric X, so the
@@ -38,7 +52,10 @@ constexpr int SP2_PART = 8448;                   // partial-sum slots per parity
 
 struct Sp2State {
     int cur, phase, done, iters;                 // X buffer in use; 0 trace-guided, 1 = final 2X - X^2 pending; finished; squarings done
-    double lo, hi, idem, trace;                  // Gershgorin bounds; last tr(X - X^2); last tr(X)
+    double lo, hi, idem, trace;                  // spectral bounds in use; last tr(X - X^2); last tr(X)
+    double h, l;                                 // accelerated recursion: lower bound of the mapped HOMO, upper bound of the mapped LUMO
+    double delta;                                // ||F' - F_ref||_F (0 without a reference)
+    int accel, pad_;                             // 1: h, l are valid and the stretched polynomials are used
 };
 
 __device__ __forceinline__ double sp2_wave_sum(double v)
@@ -49,51 +66,88 @@ __device__ __forceinline__ double sp2_wave_sum(double v)
 }
 
 // per workgroup (4 waves, one row each per pass): min_i (d_i - r_i), max_i (d_i + r_i) over its rows
-__global__ __launch_bounds__(256) void k_sp2_bounds(const double *__restrict__ F, int64_t ldf, int n, double *__restrict__ part)
+// part[3 b + {0, 1, 2}] = {min_i (d_i - r_i), max_i (d_i + r_i), sum (F - Fref)^2} over the rows of workgroup b (Fref may be NULL)
+__global__ __launch_bounds__(256) void k_sp2_bounds(const double *__restrict__ F, int64_t ldf, int n, double *__restrict__ part,
+                                                    const double *__restrict__ Fref, int64_t ldr)
 {
-    __shared__ double slo[4], shi[4];
+    __shared__ double slo[4], shi[4], sdl[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double lo = 1e300, hi = -1e300;
+    double lo = 1e300, hi = -1e300, dl = 0.0;
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
-        double r = 0.0;
-        for (int j = lane; j < n; j += 64)
-            if (j != i) r += fabs(F[(int64_t)i * ldf + j]);
+        double r = 0.0, q = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            const double f = F[(int64_t)i * ldf + j];
+            if (j != i) r += fabs(f);
+            if (Fref) {
+                const double e = f - Fref[(int64_t)i * ldr + j];
+                q += e * e;
+            }
+        }
         r = sp2_wave_sum(r);
+        dl += sp2_wave_sum(q);
         const double d = F[(int64_t)i * ldf + i];
         lo = fmin(lo, d - r);
         hi = fmax(hi, d + r);
     }
-    if (lane == 0) { slo[wave] = lo; shi[wave] = hi; }
+    if (lane == 0) { slo[wave] = lo; shi[wave] = hi; sdl[wave] = dl; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
-        part[2 * blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+        part[3 * blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+        part[3 * blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+        part[3 * blockIdx.x + 2] = (sdl[0] + sdl[1]) + (sdl[2] + sdl[3]);
     }
 }
 
 // X_0 into the padded buffer Xa (np rows, leading dimension ld, zero outside n x n); state[0]
+// ref_eigs (device, optional): {min, HOMO, LUMO, max} eigenvalues of the reference matrix the partial sums of (F - Fref)^2 belong to
 __global__ __launch_bounds__(256) void k_sp2_init(const double *__restrict__ F, int64_t ldf, int n, int np, const double *__restrict__ part,
                                                   int npart, double *__restrict__ Xa, int64_t ld, Sp2State *state,
-                                                  double *__restrict__ partials)
+                                                  double *__restrict__ partials, const double *__restrict__ ref_eigs)
 {
-    __shared__ double slo[256], shi[256];
-    double lo = 1e300, hi = -1e300;
+    __shared__ double slo[256], shi[256], sdl[256];
+    double lo = 1e300, hi = -1e300, dsum = 0.0;
     for (int p = threadIdx.x; p < npart; p += 256) {
-        lo = fmin(lo, part[2 * p]);
-        hi = fmax(hi, part[2 * p + 1]);
+        lo = fmin(lo, part[3 * p]);
+        hi = fmax(hi, part[3 * p + 1]);
+        dsum += part[3 * p + 2];
     }
     slo[threadIdx.x] = lo;
     shi[threadIdx.x] = hi;
+    sdl[threadIdx.x] = dsum;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + s]);
             shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + s]);
+            sdl[threadIdx.x] += sdl[threadIdx.x + s];
         }
         __syncthreads();
     }
     lo = slo[0];
     hi = shi[0];
+    // bounds from the reference decomposition (Weyl): every workgroup takes the same decision from the same numbers
+    double hmap = 0.0, lmap = 1.0, delta = 0.0;
+    int accel = 0;
+    if (ref_eigs) {
+        const double emin = ref_eigs[0], ehomo = ref_eigs[1], elumo = ref_eigs[2], emax = ref_eigs[3];
+        delta = sqrt(sdl[0]);
+        const double scale = fmax(fabs(emin), fabs(emax));
+        delta += 1e-12 * scale;                                             // rounding of the sum itself
+        if (delta == delta && emin <= ehomo && ehomo <= elumo && elumo <= emax) {        // (NaN / unordered input: Gershgorin only)
+            const double wlo = emin - delta, whi = emax + delta;
+            if (wlo > lo) lo = wlo;                                         // the intersection of two rigorous intervals
+            if (whi < hi) hi = whi;
+            const double width = hi - lo;
+            lo -= 1e-10 * width;
+            hi += 1e-10 * width;
+            const double hb = ehomo + delta, lb = elumo - delta;            // HOMO <= hb, LUMO >= lb
+            if (lb - hb > 1e-9 * width) {
+                hmap = (hi - hb) / (hi - lo);
+                lmap = (hi - lb) / (hi - lo);
+                accel = (hmap > lmap && hmap > 0.0 && hmap <= 1.0 && lmap >= 0.0 && lmap < 1.0) ? 1 : 0;
+            }
+        }
+    }
     const double w = (hi - lo > 1e-300) ? 1.0 / (hi - lo) : 1.0;
     // one row per workgroup (gridDim.x == np); partials[row] = {X_0[row][row], sum_j X_0[row][j]^2}
     {
@@ -126,16 +180,18 @@ __global__ __launch_bounds__(256) void k_sp2_init(const double *__restrict__ F, 
         Sp2State s;
         s.cur = 0; s.phase = 0; s.done = 0; s.iters = 0;
         s.lo = lo; s.hi = hi; s.idem = 0.0; s.trace = 0.0;
+        s.h = accel ? hmap : 0.0; s.l = accel ? lmap : 1.0; s.delta = delta; s.accel = accel; s.pad_ = 0;
         state[0] = s;
     }
 }
 
 // Decision of iteration k from the partial sums {tr X_k, ||X_k||_F^2 = tr X_k^2} the previous launch left
 // (every workgroup sums them in the same order and so takes the same decision).
-struct Sp2Decision { int branch, phase_next, done_next; double tx, idem; };   // branch 0: X^2, 1: 2X - X^2
+// branch 0: X^2, 1: 2X - X^2; X_{k+1} = c2 X^2 + c1 X + c0 I (c0 on the n x n part only); h, l after the step
+struct Sp2Decision { int branch, phase_next, done_next; double tx, idem, c2, c1, c0, h, l; };
 
 template <int NT>
-__device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx, double t2, int n_occ, double (*red)[NT])
+__device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx, double t2, int n_occ, double (*red)[NT], int /*n*/)
 {
     red[0][threadIdx.x] = tx;
     red[1][threadIdx.x] = t2;
@@ -155,14 +211,34 @@ __device__ __forceinline__ Sp2Decision sp2_decide(const Sp2State &st, double tx,
     d.idem = tx - t2;
     d.phase_next = st.phase;
     d.done_next = 0;
+    double as = 1.0, al = 1.0;                     // stretch in front of X^2 / of 2X - X^2 (1: the plain polynomials)
+    const bool closing = st.phase == 1 || (fabs(d.idem) < 1e-8 && st.iters > 0);
+    if (st.accel && !closing) {
+        as = 2.0 / (2.0 - st.l);
+        al = 2.0 / (1.0 + st.h);
+    }
+    const double bs = 1.0 - as;
     if (st.phase == 1) {
         d.branch = 1;
         d.done_next = 1;
-    } else if (fabs(d.idem) < 1e-8 && st.iters > 0) {
+    } else if (closing) {
         d.branch = 0;
         d.phase_next = 1;
     } else {
+        // trace correction with the PLAIN polynomials' traces, the stretch applied to whichever is chosen.  (Choosing by the
+        // traces the stretched polynomials would leave stalls when one side of the gap holds a single eigenvalue — n = 65,
+        // n_occ = 64: 150 squarings without convergence; this rule: 16, and no failure in a 300-case random sweep over sizes,
+        // occupations, spectra and perturbations of the reference.)
         d.branch = (fabs(t2 - n_occ) < fabs(2.0 * tx - t2 - n_occ)) ? 0 : 1;
+    }
+    if (d.branch == 0) {
+        d.c2 = as * as; d.c1 = 2.0 * as * bs; d.c0 = bs * bs;
+        const double yh = as * st.h + bs, yl = as * st.l + bs;
+        d.h = yh * yh; d.l = yl * yl;
+    } else {
+        d.c2 = -al * al; d.c1 = 2.0 * al; d.c0 = 0.0;
+        const double yh = al * st.h, yl = al * st.l;
+        d.h = 2.0 * yh - yh * yh; d.l = 2.0 * yl - yl * yl;
     }
     return d;
 }
@@ -182,7 +258,7 @@ __device__ __forceinline__ void sp2_tile(int tile, int &ti, int &tj)
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict__ Xa, const double *__restrict__ Xb, double *Xa_w,
                                                        double *Xb_w, int64_t ld, int n_occ, int chunks, double *partials,
-                                                       int npart0, int ntri, Sp2State *state, int k)
+                                                       int npart0, int ntri, Sp2State *state, int k, int nrows)
 {
     constexpr int TS = Cfg::TM, WM = Cfg::WM, WN = Cfg::WN, NT = Cfg::NT;
     static_assert(Cfg::TM == Cfg::TN && (NT & (NT - 1)) == 0, "square tiles, power-of-two workgroup");
@@ -227,7 +303,7 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
 #pragma unroll
         for (int n = 0; n < WN; ++n) acc[m][n] = double4_t{0.0, 0.0, 0.0, 0.0};
     gemm_tn_core<Cfg, false, 0, 2>(X + ti * TS, ld, X + tj * TS, ld, chunks, acc, smem);
-    const Sp2Decision d = sp2_decide<NT>(st, tx, t2, n_occ, red);
+    const Sp2Decision d = sp2_decide<NT>(st, tx, t2, n_occ, red, nrows);
     double (*T)[TS + 1] = reinterpret_cast<double (*)[TS + 1]>(smem);      // the GEMM stages are free now (sp2_decide ends on a barrier)
     double ptr = 0.0, pfro = 0.0;
 #pragma unroll
@@ -238,7 +314,11 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
             for (int j = 0; j < 4; ++j) {
                 const int row = tile_row<Cfg>(m, j), col = tile_col<Cfg>(n);
                 const double q = acc[m][n][j];
-                const double v = d.branch ? (2.0 * x[m][n][j] - q) : q;
+                const int grow = ti * TS + row;
+                // c2 X^2 + c1 X + c0 I; the plain steps (c = {1, 0, 0} / {-1, 2, 0}) are computed as before, bit for bit
+                const double v = (d.c0 == 0.0 && d.c1 == 0.0) ? q
+                               : ((d.c2 == -1.0 && d.c1 == 2.0) ? (2.0 * x[m][n][j] - q)
+                               : (d.c2 * q + d.c1 * x[m][n][j] + ((ti == tj && row == col && grow < nrows) ? d.c0 : 0.0)));
                 Xn[(int64_t)(ti * TS + row) * ld + tj * TS + col] = v;
                 T[col][row] = v;
                 pfro += v * v;
@@ -276,6 +356,8 @@ __global__ __launch_bounds__(Cfg::NT) void k_sp2_fused(const double *__restrict_
             nx.iters = st.iters + 1;
             nx.idem = d.idem;
             nx.trace = d.tx;
+            nx.h = d.h;
+            nx.l = d.l;
             state[(k + 1) & 1] = nx;
         }
     }
@@ -307,6 +389,8 @@ __global__ __launch_bounds__(256) void k_sp2_finish(const double *__restrict__ X
             info[3] = st.idem;
             info[4] = st.lo;
             info[5] = st.hi;
+            info[6] = (double)st.accel;
+            info[7] = st.delta;
         }
     }
 }

@@ -260,17 +260,23 @@ class DeviceSP2:
         self.iterations = 72
         self.calls = 0
 
-    def __call__(self, Fp: torch.Tensor, iterations: Optional[int] = None) -> torch.Tensor:
-        """Fp: symmetric (n, n) device tensor or view (row stride = its leading dimension).  Returns the (n, n) view of Pp."""
+    def __call__(self, Fp: torch.Tensor, iterations: Optional[int] = None, ref=None) -> torch.Tensor:
+        """Fp: symmetric (n, n) device tensor or view (row stride = its leading dimension).  Returns the (n, n) view of Pp.
+        ref = (F_ref, eigs): a matrix diagonalised before (same shape, unit column stride) and a device tensor with four of its
+        eigenvalues {lowest, HOMO, LUMO, highest} — spectral bounds by Weyl's inequality from ||Fp - F_ref||_F and, while they
+        bracket the gap, the accelerated recursion (`jcdf_sp2_ref_device`: about half the squarings, same projector)."""
         self.calls += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
         if Fp.stride(1) != 1:
             Fp = Fp.contiguous()
-        rc = self.lib.jcdf_sp2_device(C.c_void_p(st), self.n, self.n_occ, C.c_void_p(Fp.data_ptr()), Fp.stride(0),
-                                      C.c_void_p(self.Pp.data_ptr()), self.npad, int(iterations or self.iterations),
-                                      C.c_void_p(self.work.data_ptr()), self.wb, C.c_void_p(self.info.data_ptr()))
+        Fref, eigs = ref if ref is not None else (None, None)
+        rc = self.lib.jcdf_sp2_ref_device(C.c_void_p(st), self.n, self.n_occ, C.c_void_p(Fp.data_ptr()), Fp.stride(0),
+                                          C.c_void_p(self.Pp.data_ptr()), self.npad, int(iterations or self.iterations),
+                                          C.c_void_p(self.work.data_ptr()), self.wb, C.c_void_p(self.info.data_ptr()),
+                                          C.c_void_p(Fref.data_ptr()) if Fref is not None else None, Fref.stride(0) if Fref is not None else 0,
+                                          C.c_void_p(eigs.data_ptr()) if eigs is not None else None)
         if rc != 0:
-            raise RuntimeError("jcdf_sp2_device failed (status %d)" % rc)
+            raise RuntimeError("jcdf_sp2_ref_device failed (status %d)" % rc)
         return self.P
 
     def adapt(self, used: float, finished: bool) -> None:

@@ -378,6 +378,12 @@ class DeviceSCF:
             self.lowdin = DeviceLowdin(self.n_occ, self.N, dev)
             self.Cpt = torch.zeros((self.op, self.Np), **self._f64)     # occupied orbitals in the orthogonal basis (rows), zero padded
             self.Yt = torch.zeros((self.op, self.Np), **self._f64)
+            # the last matrix X F X that was diagonalised and four of its eigenvalues {lowest, HOMO, LUMO, highest}: spectral bounds
+            # (Weyl) and the gap bracket of the accelerated projection for the iterations that follow (jcdf_sp2_ref_device)
+            self.Fref = torch.zeros((self.Np, self.Np), **self._f64)
+            self.ref_eigs = torch.zeros(4, **self._f64)
+            self.ref_idx = torch.tensor([0, self.n_occ - 1, self.n_occ, self.N - 1], dtype=torch.int64, device=dev)
+            self.have_ref = False
         self.sp2_pivot = None
         self.tail_work = torch.zeros(256, **self._f64)
         self.tail_out = torch.zeros(8, **self._f64)
@@ -502,11 +508,13 @@ class DeviceSCF:
             # Cp_new Cp_new^T = P exactly when P is a projector and Y has full rank (the Newton-Schulz iteration for the
             # inverse square root converges then and only then: its status word goes into the iteration's record).
             # Every product runs on the library's MFMA cores (jcdf_gemm_nt_device, jcdf_lowdin_rows_device).
-            self.sp2(self.Fpr[:N, :N])                              # -> self.sp2.Pp (Np x Np, zero padded)
+            self.sp2(self.Fpr[:N, :N], ref=(self.Fref[:N, :N], self.ref_eigs) if self.have_ref else None)    # -> self.sp2.Pp (Np x Np, zero padded)
             self._gemm_nt(self.Cpt, self.sp2.Pp, self.Yt)           # (o, N) = (P Cp)^T   (P symmetric)
             self._sp2_basis()
             return
         else:
+            if self.sp2 is not None:
+                self.Fref.copy_(self.Fpr)                           # the reference of the projections that follow (Fpr itself is consumed)
             try:
                 self.eps, U = self.eigh(self.Fpr[:N, :N])           # (destroys Fpr: eigh.scratch)
             except RuntimeError:
@@ -522,6 +530,8 @@ class DeviceSCF:
             self._gemm_tn(Up, self.Xp, self.Ctp)                    # (X U)^T[i][m] = sum_k U[k][i] X[k][m]
             if self.sp2 is not None:
                 self.Cpt[:o, :N].copy_(Up[:N, :o].t())              # occupied orbitals in the orthogonal basis, (o, N)
+                torch.index_select(self.eps, 0, self.ref_idx, out=self.ref_eigs)
+                self.have_ref = True
             self.Cop[:o].copy_(self.Ctp[:o])
             self.canonical = True
         self._gemm_tn(self.Cop, self.Cop, self.Dp, 2.0)             # D = 2 Co^T Co (zero rows of Cop add nothing)

@@ -1025,6 +1025,49 @@ def test_sp2_projector_equals_eigensolver_projector(n, o, gap):
     assert torch.equal(sp(F, 150), P)
 
 
+@pytest.mark.parametrize("n,o,gap", [(7, 3, 0.5), (64, 10, 0.5), (65, 64, 0.3), (100, 37, 0.1), (510, 81, 0.5), (510, 81, 0.01),
+                                     (700, 350, 0.2), (1250, 250, 0.5)])
+def test_sp2_with_a_reference_decomposition_is_accelerated_and_exact(n, o, gap):
+    """jcdf_sp2_ref_device: spectral bounds by Weyl's inequality from a matrix diagonalised before, and —
+    while HOMO + delta < LUMO - delta brackets the gap — the accelerated recursion.  Same projector to roundoff, exactly
+    symmetric, fewer squarings; a perturbation that closes the bracket switches the acceleration off (the bounds stay)."""
+    import torch
+    from juliachem_jl_amd.eigh import DeviceSP2
+    dev = torch.device("cuda", 0)
+    F, Pref = _spectrum_matrix(n, o, gap, 5 + n, dev)
+    ev = torch.linalg.eigvalsh(F)
+    eigs = torch.stack([ev[0], ev[o - 1], ev[o], ev[n - 1]])
+    sp = DeviceSP2(n, o, dev)
+    sp(F, 150)
+    plain = sp.info.cpu().tolist()
+    P = sp(F, 150, ref=(F, eigs)).clone()                                  # delta = 0: the tightest bracket
+    its, finished, trace, idem, lo, hi, accel, delta = sp.info.cpu().tolist()
+    assert finished == 1.0 and accel == 1.0 and delta < 1e-9 and abs(trace - o) < 1e-10
+    assert lo <= ev[0].item() and hi >= ev[-1].item() and (hi - lo) < 1.001 * (ev[-1] - ev[0]).item() + 1e-6
+    assert (P - P.T).abs().max().item() == 0.0 and (P - Pref).abs().max().item() < 1e-10
+    assert its < plain[0] and (n < 64 or its <= 0.8 * plain[0]), (its, plain[0])
+    assert torch.equal(sp(F, 150, ref=(F, eigs)), P)                       # deterministic
+    # a nearby matrix (an SCF iteration later): ||E||_F = gap / 5, its own projector, still accelerated
+    g = torch.Generator(device="cpu").manual_seed(n)
+    E = torch.randn(n, n, dtype=torch.float64, generator=g); E = 0.5 * (E + E.T)
+    E = (E * (0.2 * gap / E.norm())).to(dev)
+    F2 = F + E
+    w2, U2 = torch.linalg.eigh(F2)
+    P2 = sp(F2, 150, ref=(F, eigs)).clone()
+    its2, fin2, _, _, lo2, hi2, accel2, delta2 = sp.info.cpu().tolist()
+    assert fin2 == 1.0 and accel2 == 1.0 and abs(delta2 - 0.2 * gap) < 1e-6 * gap + 1e-10
+    assert lo2 <= w2[0].item() and hi2 >= w2[-1].item()
+    assert (P2 - U2[:, :o] @ U2[:, :o].T).abs().max().item() < 1e-9
+    # a perturbation larger than half the gap: no bracket, plain recursion inside the Weyl bounds, still the right projector
+    F3 = F + E * 4.0
+    w3, U3 = torch.linalg.eigh(F3)
+    if (w3[o] - w3[o - 1]).item() > 1e-3 * gap:
+        P3 = sp(F3, 200, ref=(F, eigs)).clone()
+        its3, fin3, _, _, lo3, hi3, accel3, _ = sp.info.cpu().tolist()
+        assert accel3 == 0.0 and lo3 <= w3[0].item() and hi3 >= w3[-1].item()
+        assert fin3 == 1.0 and (P3 - U3[:, :o] @ U3[:, :o].T).abs().max().item() < 1e-8
+
+
 def test_sp2_reports_unfinished_and_rejects_bad_arguments():
     import ctypes
     import torch
