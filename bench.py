@@ -304,7 +304,12 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
            "fock_build_useful_tflops": fock_useful_flops(N, Q, o, P) / (fock_ms * 1e-3) / 1e12,
            "fock_build_tflops_dense_formula": fock_alg_flops(N, Q, o) / (fock_ms * 1e-3) / 1e12,
            "setup_s": t_setup, "eigensolver": rep, "eigensolver_stages": eig_ms, "density_solver": scf.density_solver,
-           "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries}
+           "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries,
+           "sp2_accelerated_steps": scf.sp2_accelerated, "sp2_reference_refreshes": scf.sp2_refreshes}
+    if scf.sp2 is not None:
+        si = scf.sp2.info.cpu().tolist()                     # the last projection of the run
+        out["sp2_last_projection"] = {"squarings": si[0], "finished": si[1], "accelerated": si[6], "delta_to_reference": si[7],
+                                      "spectral_bounds": [si[4], si[5]], "squarings_enqueued": scf.sp2.iterations}
     if args.in_process:
         out["group"] = dict(gtm, transport=fb.g.transport())
     fb.close()
@@ -627,7 +632,10 @@ def main(argv=None):
                "replicated_ms": alt_s / args.steps * 1e3 - alt_fock_ms - alt_coll,
                "kernels_ms": {k: v["seconds"] / v["n"] * 1e3 for k, v in alt_k.items()}, "sp2_steps": scf2.sp2_steps, "sp2_fallbacks": scf2.sp2_fallbacks,
                "energy_minus_eigh": scf2.trail[-1][1] - scf.trail[-1][1],
-               "sp2_basis_retries": scf2.sp2_basis_retries,
+               "sp2_last_projection": (lambda si: {"squarings": si[0], "finished": si[1], "accelerated": si[6], "delta_to_reference": si[7],
+                                                   "spectral_bounds": [si[4], si[5]], "squarings_enqueued": scf2.sp2.iterations})(scf2.sp2.info.cpu().tolist())
+               if scf2.sp2 is not None else None,
+               "sp2_basis_retries": scf2.sp2_basis_retries, "sp2_accelerated_steps": scf2.sp2_accelerated, "sp2_reference_refreshes": scf2.sp2_refreshes,
                "note": "optional scf flag density_solver=sp2: occupied-space projector by matrix squarings (jcdf_sp2_device) instead "
                        "of the per-iteration eigensolve, basis by Newton-Schulz (jcdf_lowdin_rows_device): every product on the "
                        "library's own cores; same energies; not the default, not `value`"}

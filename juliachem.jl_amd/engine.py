@@ -387,7 +387,10 @@ class DeviceSCF:
         self.sp2_pivot = None
         self.tail_work = torch.zeros(256, **self._f64)
         self.tail_out = torch.zeros(8, **self._f64)
-        self.sp2_steps = self.sp2_fallbacks = self.sp2_basis_retries = 0
+        self.sp2_steps = self.sp2_fallbacks = self.sp2_basis_retries = self.sp2_refreshes = 0
+        self.sp2_refresh = False                 # next step: one eigensolve to renew the reference decomposition of the projections
+        self.sp2_refresh_below = 0.05            # ... asked for when the density change falls below this while the recursion is not accelerated
+        self.sp2_accelerated = 0                 # projections that ran the accelerated recursion
         self.sp2_reasons = {}
         self.sp2_skip = True                     # first step, and while the density still changes wholesale: eigensolver
         self.canonical = True                    # self.C / self.eps are the eigenvectors / eigenvalues of self.F
@@ -580,9 +583,11 @@ class DeviceSCF:
             # trouble flags are OR-ed over the ranks, everything else is rank 0's record — ONE small all-reduce (sum): the
             # other ranks contribute zeros to the record part, every rank its own flags
             rec, dist = self.tail_out, self.fb.dist
-            buf = torch.zeros(11, dtype=torch.float64, device=rec.device)
+            buf = torch.zeros(13, dtype=torch.float64, device=rec.device)
             if self.fb.rank == 0:
                 buf[:8] = rec
+                if use_sp2:
+                    buf[11:13] = self.sp2.info[6:8]                  # accelerated?, ||F' - F_ref||: rank 0's, like the rest of the record
             buf[8] = (rec[3] != 0).to(torch.float64)
             if use_sp2:
                 # two separate flags: trouble with the PROJECTOR (squarings not finished / trace off / not finite)
@@ -597,7 +602,11 @@ class DeviceSCF:
             if use_sp2:
                 rec[4] = torch.where(buf[9] != 0, torch.zeros_like(rec[4]), rec[4])     # some rank's projector failed: unfinished everywhere
                 rec[6] = torch.where(buf[10] != 0, torch.zeros_like(rec[6]), rec[6])    # some rank's basis failed: retried everywhere
-        return self.tail_out.cpu().tolist()
+                return torch.cat([rec, buf[11:13]]).cpu().tolist()
+            return rec.cpu().tolist() + [0.0, 0.0]
+        if use_sp2:
+            return torch.cat([self.tail_out, self.sp2.info[6:8]]).cpu().tolist()    # + {accelerated, delta} of the projection: still ONE copy
+        return self.tail_out.cpu().tolist() + [0.0, 0.0]
 
     def canonical_orbitals(self) -> None:
         """Eigenvectors / eigenvalues of the current Fock matrix into self.C / self.eps (what the reference has after
@@ -695,10 +704,13 @@ class DeviceSCF:
         D_old = self.Dbuf[self.di]
         self.di ^= 1                                               # _diag writes the new density into the other buffer
         self._mark("damp")
-        use_sp2 = self.sp2 is not None and not self.sp2_skip
+        use_sp2 = self.sp2 is not None and not self.sp2_skip and not self.sp2_refresh
+        if self.sp2_refresh:                                       # this step's eigensolve renews the reference (Fref, frontier eigenvalues)
+            self.sp2_refresh = False
+            self.sp2_refreshes += 1
         self._diag(use_sp2)
         self._mark("diag")
-        e_h, drms, faulty, eig_bad, finished, trace, pivot, used = self._tail(D_old, use_sp2)
+        e_h, drms, faulty, eig_bad, finished, trace, pivot, used, accel, ref_delta = self._tail(D_old, use_sp2)
         if faulty:                                                 # "Faulty DIIS!" SCF.jl:493-499 (seen one sync later)
             self.B_dim = 2
             self.diis_flag.zero_()
@@ -712,7 +724,7 @@ class DeviceSCF:
                 self.sp2_basis_retries += 1
                 self.lowdin.steps = 40
                 self._sp2_basis()
-                e_h, drms, _, _, _, _, pivot, _ = self._tail(D_old, True)
+                e_h, drms, _, _, _, _, pivot, _ = self._tail(D_old, True)[:8]
             self.lowdin.adapt(pivot if math.isfinite(pivot) else 0.0)
             good = proj_ok and pivot >= 1.0 and math.isfinite(e_h)
             if not good:                                           # not converged in the squarings enqueued / basis lost: eigensolve
@@ -729,6 +741,15 @@ class DeviceSCF:
             self.eigh.check()                                      # the failing one with the vendor solver (counted, solver_report)
             self._diag(False)
             e_h, drms = self._tail(D_old, False)[:2]
+        if use_sp2:
+            self.sp2_accelerated += int(accel == 1.0)
+            # The accelerated recursion (half the squarings) needs ||F' - F_ref|| below half the HOMO-LUMO gap of the last matrix
+            # that was DIAGONALISED — normally the one of the first iteration, far from where the SCF has moved.  Once the density
+            # has settled (its change below a threshold that drops tenfold with every request) one eigensolve is spent on a new
+            # reference: 7 ms against ~1.4 ms saved in every projection that follows at N = 1250.
+            if accel != 1.0 and drms < self.sp2_refresh_below and not self.sp2_skip:
+                self.sp2_refresh = True
+                self.sp2_refresh_below = 0.1 * drms
         self.sp2_skip = not (drms < 15.0)       # occupied space still turning by ~90 degrees somewhere: no basis to project
         E = e_h + self.E_nuc
         dE = E - self.E_old

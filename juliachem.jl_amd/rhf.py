@@ -143,7 +143,7 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
            "Orbital Energies": eps, "Iterations": it, "Nuclear Repulsion": E_nuc, "Trail": list(scf.trail),
            "Kernel Stats": fb.h.kernel_stats(), "Device Bytes": fb.h.device_bytes(), "Iteration Times": it_times,
            "Eigensolver": scf.solver_report(),
-           "Density Solver": {"name": scf.density_solver, "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries,
+           "Density Solver": {"name": scf.density_solver, "sp2_steps": scf.sp2_steps, "sp2_fallbacks": scf.sp2_fallbacks, "sp2_basis_retries": scf.sp2_basis_retries, "sp2_accelerated_steps": scf.sp2_accelerated, "sp2_reference_refreshes": scf.sp2_refreshes,
                               "sp2_fallback_reasons": dict(scf.sp2_reasons)}}
     fb.close()
     eng.close()
