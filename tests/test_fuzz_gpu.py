@@ -161,3 +161,95 @@ def test_random_symmetric_matrix_eigensolve(i):
     assert np.abs(w - wref).max() < 4e-14 * norm * max(1.0, np.sqrt(n)), (n, kind)
     assert np.abs(U.T @ U - np.eye(n)).max() < 1e-13, (n, kind)
     assert np.abs(A @ U - U * w[None, :]).max() < 8.0 * max(np.abs(A @ Uref - Uref * wref[None, :]).max(), 1e-15 * norm), (n, kind)
+
+
+N_GROUP = int(os.environ.get("JCDF_FUZZ_GROUP_CASES", "12"))
+
+
+@pytest.mark.parametrize("i", range(N_GROUP))
+def test_random_case_through_the_multi_device_group(i):
+    """The same random draws through jcdf_group_* (round 4): the shards as members of one group on the one GPU ("peer" transport;
+    a one-member group also through RCCL) — metric factored once, every block pushed once, C uploaded once, F reduced on the
+    device: equal to the oracle at 1e-11 and BIT-EQUAL to the fixed-order sum of independent handles, twice in a row."""
+    c = _draw(1000 + i)
+    rng = np.random.default_rng([SEED, 77, i])
+    N, Q, o = c["N"], c["Q"], c["o"]
+    s = synthetic.make(N, Q, o, seed=c["seed"], kept_fraction=c["kept"] if c["mode"] != "dense" else None)
+    if c["mode"] == "cluster":
+        s.mask = synthetic.cluster_mask(N, min(c["kept"], 0.4), np.random.default_rng(c["seed"] + 1), per_site=3)
+    Co = s.C[:, :o]
+    B = orc.calculate_B(s.J2c, s.T)
+    if c["mode"] == "dense":
+        sd, pq = None, (None, None)
+        ref = s.H + orc.df_rhf_fock_build_BLAS(B, Co)
+        Tsrc = np.asfortranarray(s.T.reshape(Q, N * N, order="F"))
+    else:
+        sd = orc.get_screening_metadata(s.mask)
+        pq = (sd.pq_p, sd.pq_q)
+        Bp = orc.pack_three_center(B, sd)
+        ref = s.H + orc.df_rhf_fock_build_screened(Bp, Co, sd, n_blocks=c["n_blocks"] or 10, screen_exchange=c["n_blocks"] > 0)
+        Tsrc = np.asfortranarray(orc.pack_three_center(s.T, sd))
+    want = int(rng.choice([1, 2, 3, 5]))
+    offs = [int(x) for x in orc.shard_offsets(s.aux_shell_nbas, want)]
+    offs = sorted(set(offs))                                        # ranks the reference rule leaves without aux shells hold nothing
+    n = len(offs) - 1
+    transport = str(rng.choice(["peer", "rccl"])) if n == 1 else "peer"
+    g = jc.JCDFGroup([0] * n)
+    g.set_transport(transport)
+    for m in g.members:
+        for k, v in c["tuning"].items():
+            m.set_tuning(k, v)
+    if c["n_blocks"]:
+        g.set_exchange_screening(c["n_blocks"])
+    g.configure(N, Q, offs, o, *pq)
+    g.set_metric(np.tril(s.J2c))
+    order = list(range(n))
+    rng.shuffle(order)                                              # blocks may arrive in any order
+    for b in order:
+        g.push_three_center(offs[b], offs[b + 1], np.asfortranarray(Tsrc[offs[b]:offs[b + 1]]))
+    g.set_core_hamiltonian(s.H)
+    F, t, gt = g.fock_build(Co)
+    assert _rel(F, ref) < RTOL, (c, n, transport)
+    total = None
+    for r in range(n):
+        h = jc.JCDFHandle(0)
+        for k, v in c["tuning"].items():
+            h.set_tuning(k, v)
+        if c["n_blocks"]:
+            h.set_exchange_screening(c["n_blocks"])
+        h.configure(N, Q, offs[r], offs[r + 1], o, *pq)
+        h.set_metric(np.tril(s.J2c))
+        for b in order:                                             # (B accumulates in push order: the same order, the same bits)
+            h.push_three_center(offs[b], offs[b + 1], np.asfortranarray(Tsrc[offs[b]:offs[b + 1]]))
+        h.set_core_hamiltonian(s.H if r == 0 else None)
+        Fh, _ = h.fock_build(Co)
+        total = Fh if total is None else total + Fh
+        h.close()
+    assert np.array_equal(F, total), (c, n, transport)
+    F2, _, _ = g.fock_build(Co)
+    assert np.array_equal(F2, F)
+    g.close()
+
+
+@pytest.mark.parametrize("i", range(8))
+def test_random_symmetric_matrix_compact_wy_back_transformation(i, monkeypatch):
+    """The blocked compact-WY back-transformation (what sizes above 1536 use) forced on random matrices of random structure and
+    size: every block count and padding edge of jcdf_ormtr_device against LAPACK."""
+    import torch
+    from juliachem_jl_amd.eigh import DeviceEigh
+    monkeypatch.setenv("JCDF_EIGH_WY", "1")
+    n, kind, A = _draw_matrix(500 + i)
+    if n < 3:
+        n, kind, A = _draw_matrix(900 + i)
+    dev = torch.device("cuda", 0)
+    eg = DeviceEigh(n, dev)
+    assert eg.ok and not eg.with_q
+    w, U = eg(torch.as_tensor(A, device=dev))
+    torch.cuda.synchronize()
+    assert eg.check() and eg.fallbacks == 0, (n, kind, getattr(eg, "reason", ""))
+    w = w.cpu().numpy(); U = U.cpu().numpy()
+    wref, Uref = np.linalg.eigh(A)
+    norm = max(np.abs(wref).max(), 1e-300)
+    assert np.abs(w - wref).max() < 4e-14 * norm * max(1.0, np.sqrt(n)), (n, kind)
+    assert np.abs(U.T @ U - np.eye(n)).max() < 1e-13, (n, kind)
+    assert np.abs(A @ U - U * w[None, :]).max() < 8.0 * max(np.abs(A @ Uref - Uref * wref[None, :]).max(), 1e-15 * norm), (n, kind)
