@@ -86,7 +86,19 @@ def run(atoms: Sequence[Dict], charges: Dict[str, float], basis: Dict[str, List[
     # df_exchange_screen (ScreenedDF.jl:431-447, 459-545): meaningful on the packed map only (a dense map keeps every block)
     xs = exchange_screen_blocks(opts) if not dense else 0
     jc_timing.non_timing_data["df_exchange_screen_blocks"] = str(xs)
-    fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq, exchange_screen_blocks=xs)
+    if opts.num_devices > 1 and world == 1:
+        # scf flag num_devices of the reference (one rank, several GPUs: GPUDF.jl:188-277): ONE process, the devices behind the
+        # C ABI's multi-device group — the SCF loop on the first device, every Fock build sharded over all of them and reduced
+        # on the devices (engine.GroupFockBuilder)
+        from .df import _physical_device
+        from .engine import GroupFockBuilder
+        first = 0 if device is None else int(device)
+        fb = GroupFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, [_physical_device(first + d) for d in range(opts.num_devices)], pq=pq,
+                              exchange_screen_blocks=xs, transport=flags.get("group_transport"))
+        jc_timing.non_timing_data["GPU_reduce_transport"] = fb.g.transport()
+    else:
+        fb = DeviceFockBuilder(N, Q, n_occ, eng.aux.shell_nbas, device=device, pq=pq, exchange_screen_blocks=xs)
+    jc_timing.non_timing_data[JCTC.GPU_num_devices] = str(opts.num_devices if world == 1 else 1)
     fb.set_metric(J2c)
     fb.set_core_hamiltonian(H)
     t_eri = 0.0

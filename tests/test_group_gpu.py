@@ -239,3 +239,25 @@ def test_reference_shaped_operator_on_two_ranks(num_devices):
         own0 = sum(rows[:num_devices])
         assert (sent, recv) == ((own0 * P, 0) if rank == 0 else (0, own0 * P))
         assert transport.startswith("peer") == (num_devices == 2)
+
+
+@pytest.mark.parametrize("solver", ["eigh", "sp2"])
+def test_rhf_run_with_num_devices_3_is_one_process_over_a_group(solver, monkeypatch):
+    """rhf.run with the reference's scf flag num_devices (one rank, several GPUs; here three members on the one GPU): the device
+    SCF loop on the first device, every Fock build through jcdf_group_fock_build_device_ld — same energy and iteration count as
+    the one-device run to 1e-10 Eh, with either density solver."""
+    import json, os
+    from juliachem_jl_amd import rhf
+    from water_case import GOLDEN, FIXTURES
+    monkeypatch.setenv("JCDF_ALLOW_DEVICE_WRAP", "1")
+    g = json.load(open(os.path.join(GOLDEN, FIXTURES["ccpvdz"])))
+    atoms = list(g["atoms"]) + [{"symbol": a["symbol"], "center": [a["center"][0] + 0.3, a["center"][1] + 7.0, a["center"][2] + 1.1]}
+                                for a in g["atoms"]]
+    f = {"dele": 1e-8, "rmsd": 1e-8, "niter": 60, "density_solver": solver}
+    one = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], f)
+    three = rhf.run(atoms, g["charges"], g["basis"], g["aux_basis"], dict(f, num_devices=3))
+    assert three["Converged?"] and three["Iterations"] == one["Iterations"]
+    assert abs(three["Energy"] - one["Energy"]) < 1e-10
+    assert three["Timings"].non_timing_data["GPU_num_devices"] == "3"
+    assert three["Timings"].non_timing_data["GPU_reduce_transport"].startswith("peer")
+    assert np.abs(three["Density"] - one["Density"]).max() < 1e-8
