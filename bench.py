@@ -664,7 +664,8 @@ def main(argv=None):
                "dense_map": measure_w50(args, world, rank, local, dev, barrier, None),
                # the same screened problem with the optional spectral-projection density solver (no eigensolve per
                # iteration): what the replicated part costs strong scaling — informational, like `alt`
-               "screened_13pct_sp2": measure_w50(args, world, rank, local, dev, barrier, 0.13, density_solver="sp2")}
+               "screened_13pct_sp2": measure_w50(args, world, rank, local, dev, barrier, 0.13, density_solver="sp2"),
+               "dense_map_sp2": measure_w50(args, world, rank, local, dev, barrier, None, density_solver="sp2")}
 
     # BASELINE config 5: the glycine-oligomer / cc-pVTZ shape (N = 1915: above the size whose Q fits the tridiagonalisation
     # kernel — two-kernel tridiagonalisation + compact-WY back-transformation, no vendor kernel), 30 %-kept map; never `value`

@@ -54,7 +54,7 @@ def test_bench_prints_the_contract_line():
     assert 0.11 < w50["screened_13pct"]["kept_pair_fraction"] < 0.16 and w50["dense_map"]["kept_pair_fraction"] == 1.0
     assert w50["screened_13pct"]["device_GB_rank0"] < 0.4 * w50["dense_map"]["device_GB_rank0"]
     assert w50["screened_13pct"]["kernels_ms"]["k_exchange_W"] < 0.3 * w50["dense_map"]["kernels_ms"]["k_exchange_W"]
-    for kind in ("screened_13pct", "dense_map", "screened_13pct_sp2"):
+    for kind in ("screened_13pct", "dense_map", "screened_13pct_sp2", "dense_map_sp2"):
         pj = w50[kind]["projected_8gpu"]
         assert "projection" in pj["note"] and 1.0 < pj["speedup_over_1gpu"] < 8.0
         assert abs(pj["ms_per_step"] - (pj["fock_build_ms"] + pj["replicated_ms"] + pj["allreduce_ms_assumed"])) < 1e-9
