@@ -309,7 +309,12 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
     if scf.sp2 is not None:
         si = scf.sp2.info.cpu().tolist()                     # the last projection of the run
         out["sp2_last_projection"] = {"squarings": si[0], "finished": si[1], "accelerated": si[6], "delta_to_reference": si[7],
-                                      "spectral_bounds": [si[4], si[5]], "squarings_enqueued": scf.sp2.iterations}
+                                      "spectral_bounds": [si[4], si[5]], "squarings_enqueued": scf.sp2.iterations,
+                                      "last_density_change": scf.trail[-1][3]}
+        if si[6] != 1.0:
+            out["sp2_last_projection"]["note"] = ("not accelerated: the distance to the last diagonalised matrix exceeds half its HOMO-LUMO gap "
+                                                  "(a synthetic SCF that has not settled — see last_density_change — keeps it there; "
+                                                  "profiles/r04_sp2_w50_trend.txt)")
     if args.in_process:
         out["group"] = dict(gtm, transport=fb.g.transport())
     fb.close()

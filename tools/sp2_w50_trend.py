@@ -14,12 +14,18 @@ from juliachem_jl_amd.engine import DeviceFockBuilder, DeviceSCF
 dev = torch.device("cuda", 0)
 N, Q, o = synthetic.CONFIGS["w50"]
 rng = np.random.default_rng(synthetic.SEED + 50)
-sd = jc.get_screening_metadata(synthetic.cluster_mask(N, 0.13, rng))
-p, q = jc.packed_pq_lists(sd)
+KEPT = float(sys.argv[2]) if len(sys.argv) > 2 else 0.13          # 0: the unscreened map
+if KEPT > 0:
+    sd = jc.get_screening_metadata(synthetic.cluster_mask(N, KEPT, rng))
+    p, q = jc.packed_pq_lists(sd)
+    pq = (p, q)
+else:
+    p = np.repeat(np.arange(N, dtype=np.int64), N); q = np.tile(np.arange(N, dtype=np.int64), N)
+    pq = (None, None)
 P = len(p)
 shells = synthetic.aux_shells(Q, rng)
 Hs = rng.standard_normal((N, N)); H = 0.5 * (Hs + Hs.T)
-fb = DeviceFockBuilder(N, Q, o, shells, device=0, pq=(p, q))
+fb = DeviceFockBuilder(N, Q, o, shells, device=0, pq=pq)
 fb.set_core_hamiltonian(H)
 g = torch.Generator(device=dev); g.manual_seed(synthetic.SEED + 1000)
 g1 = torch.randn((Q, N), dtype=torch.float64, device=dev, generator=g) * 0.05
