@@ -523,6 +523,12 @@ def main(argv=None):
                          "bench.py starts its own ranks)\n" % (args.gpus, world, args.gpus))
         raise SystemExit(2)
 
+    # ONE JSON line on stdout and nothing else: libraries that print to file descriptor 1 (RCCL writes its version banner there when
+    # a communicator is created) are sent to stderr for the whole run; the line goes out through the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import juliachem_jl_amd as jc
     from juliachem_jl_amd import synthetic
@@ -774,7 +780,9 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(N, Q, o)
             out["speedup_vs_cpu_iteration"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_fock_build"] = out["cpu_baseline"]["fock_build_s"] / (fock_ms * 1e-3)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         torch.distributed.destroy_process_group()
 

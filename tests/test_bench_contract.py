@@ -16,6 +16,8 @@ def test_bench_prints_the_contract_line():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # ... and NOTHING else on stdout (RCCL prints a version banner to descriptor 1 when a communicator is created: it must end on stderr)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[:600]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
