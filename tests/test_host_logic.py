@@ -66,6 +66,18 @@ def test_no_cpu_fallback():
     assert e.value.code == 3 and "no CPU fallback" in str(e.value)
 
 
+def test_no_cpu_fallback_for_the_group_either():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(jc.JCDFError) as e:
+        jc.JCDFGroup([0, 1])
+    assert e.value.code == 3 and "no CPU fallback" in str(e.value) and "member 0" in str(e.value)
+    with pytest.raises(jc.JCDFError) as e:
+        jc.JCDFGroup(list(range(17)))                      # JCDF_GROUP_MAX_DEVICES = 16
+    assert e.value.code == 1
+
+
 def test_product_package_never_imports_oracle():
     pkg = os.path.join(ROOT, "juliachem.jl_amd")
     for dp, _, files in os.walk(pkg):
