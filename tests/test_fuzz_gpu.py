@@ -253,3 +253,46 @@ def test_random_symmetric_matrix_compact_wy_back_transformation(i, monkeypatch):
     assert np.abs(w - wref).max() < 4e-14 * norm * max(1.0, np.sqrt(n)), (n, kind)
     assert np.abs(U.T @ U - np.eye(n)).max() < 1e-13, (n, kind)
     assert np.abs(A @ U - U * w[None, :]).max() < 8.0 * max(np.abs(A @ Uref - Uref * wref[None, :]).max(), 1e-15 * norm), (n, kind)
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_random_structured_matrix_above_the_one_exchange_size(i):
+    """Sizes 1537 .. 2040 (two-kernel tridiagonalisation + compact-WY back-transformation, no vendor routine) on matrices of random
+    STRUCTURE — graded, clustered spectra, decoupled blocks (zero sub-columns in both kernels and across their hand-over), low rank,
+    already tridiagonal — against LAPACK."""
+    import torch
+    from juliachem_jl_amd.eigh import DeviceEigh
+    rng = np.random.default_rng([SEED, 424242, i])
+    n = int(rng.integers(1537, 2041))
+    kind = ["gaussian", "graded", "clustered", "blocks", "lowrank", "tridiagonal"][i]
+    R = rng.standard_normal((n, n))
+    if kind == "gaussian":
+        A = 0.5 * (R + R.T)
+    elif kind == "graded":
+        d = np.sqrt(np.logspace(-4, 2, n)); rng.shuffle(d)
+        A = d[:, None] * (0.5 * (R + R.T)) * d[None, :]
+    elif kind == "clustered":
+        Qm, _ = np.linalg.qr(R)
+        w = rng.choice(rng.standard_normal(n // 20), size=n)
+        A = (Qm * w[None, :]) @ Qm.T; A = 0.5 * (A + A.T)
+    elif kind == "blocks":
+        A = np.zeros((n, n)); k = 0
+        while k < n:
+            m = int(min(n - k, rng.integers(1, 300)))
+            S = rng.standard_normal((m, m)); A[k:k + m, k:k + m] = 0.5 * (S + S.T); k += m
+    elif kind == "lowrank":
+        U = rng.standard_normal((n, 4)); A = U @ U.T + np.diag(rng.standard_normal(n) * 1e-3)
+    else:
+        A = np.diag(rng.standard_normal(n)); e = rng.standard_normal(n - 1); A += np.diag(e, 1) + np.diag(e, -1)
+    dev = torch.device("cuda", 0)
+    eg = DeviceEigh(n, dev)
+    assert eg.ok and not eg.with_q
+    w, U = eg(torch.as_tensor(A, device=dev))
+    torch.cuda.synchronize()
+    assert eg.check() and eg.fallbacks == 0, (n, kind, getattr(eg, "reason", ""))
+    w = w.cpu().numpy(); U = U.cpu().numpy()
+    wref, Uref = np.linalg.eigh(A)
+    norm = max(np.abs(wref).max(), 1e-300)
+    assert np.abs(w - wref).max() < 4e-14 * norm * np.sqrt(n), (n, kind)
+    assert np.abs(U.T @ U - np.eye(n)).max() < 1e-13, (n, kind)
+    assert np.abs(A @ U - U * w[None, :]).max() < 8.0 * max(np.abs(A @ Uref - Uref * wref[None, :]).max(), 1e-15 * norm), (n, kind)
