@@ -182,3 +182,23 @@ def test_group_reduce_plan_partitions_the_fock_matrix():
     for bad in ((0, 2), (10, 0), (10, 17)):
         with pytest.raises(jc.JCDFError):
             jc.group_reduce_plan(*bad)
+
+
+def test_headers_are_plain_c():
+    """include/jcdf.h and include/jcint.h are a C ABI: they compile as C99 (-pedantic -Werror) with nothing but <stdint.h>, and a C
+    program that uses the declared types links against the library's exports."""
+    import subprocess, tempfile
+    src = ('#include "jcdf.h"\n#include "jcint.h"\n'
+           'int main(void) { jcdf_timings t; jcdf_group_timings g; jcdf_handle *h = 0; jcdf_group *gr = 0; (void)t; (void)g;\n'
+           '  if (jcdf_abi_version() < 1002) return 2;\n'
+           '  if (jcdf_group_reduce_plan(100, 2, (int64_t[3]){0, 0, 0}) != 256) return 3;\n'
+           '  (void)jcdf_last_error(h); (void)jcdf_group_last_error(gr); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "abi.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "abi")
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), c, "-o", exe,
+                        "-L", libdir, "-ljcdf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True)
+        r = subprocess.run([exe], capture_output=True)
+        assert r.returncode == 0, (r.returncode, r.stderr[-500:])
