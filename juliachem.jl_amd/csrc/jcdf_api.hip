@@ -2135,7 +2135,6 @@ int32_t jcdf_stedc_device(void *stream, int64_t n, double *d_D, double *d_E, dou
     if (work_bytes < wk.bytes) return JCDF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (ensure_device_attributes() != hipSuccess) return JCDF_ERR_HIP;
-    if (hipMemsetAsync(wk.info, 0, 256, st) != hipSuccess) return JCDF_ERR_HIP;
     const int L = (int)plan->levels.size();
     // ping-pong so that the last level writes into the caller's buffers: eigenvalues end in d_D, vectors in d_Z
     double *Za = (L % 2 == 0) ? d_Z : wk.Zb, *Zn = (L % 2 == 0) ? wk.Zb : d_Z;

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_dc_norm(const double *__restrict__ d, c
     }
     red[threadIdx.x] = mx;
     __syncthreads();
-    if (threadIdx.x == 0 && bad) *info = 2;             // every later kernel of this call returns at once (k_dc_leaf included)
+    // the call's info word starts here (no separate memset launch): 2 = non-finite input, every later kernel of this call returns
+    // at once (k_dc_leaf included); 0 otherwise, until a leaf reports its iteration cap (1)
+    if (threadIdx.x == 0) *info = bad ? 2 : 0;
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
         __syncthreads();

@@ -26,9 +26,9 @@ struct GroupSrc {
     const double *p[JCDF_GROUP_MAX_DEVICES];
 };
 
-// dst[off + e] = sum_{j < n} src.p[j][off + e] (j ascending), e < len.  dst may be src.p[self] (read before written by
-// the same thread).  off is a multiple of 256 elements: 16-byte loads.
-__global__ __launch_bounds__(256) void k_group_reduce_slice(GroupSrc src, int n, double *__restrict__ dst, int64_t off, int64_t len)
+// dst[off + e] = sum_{j < n} src.p[j][off + e] (j ascending), e < len.  dst IS src.p[self] (in place: an element is read and
+// written by the same thread, so no __restrict__ on it).  off is a multiple of 256 elements: 16-byte loads.
+__global__ __launch_bounds__(256) void k_group_reduce_slice(GroupSrc src, int n, double *dst, int64_t off, int64_t len)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
     for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; e < len; e += stride) {
