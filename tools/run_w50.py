@@ -2,7 +2,7 @@
 """A real molecule at the scale of BASELINE config 4: (H2O)50 (geometry of the reference's example_inputs/w50.json,
 tests/golden/w50_geometry.json) / cc-pVDZ / cc-pVDZ-RIFIT (basis data of the reference's water log), DF-RHF on one
 MI355X through rhf.run: 1250 AO, 4800 auxiliary functions, Schwarz-screened packed layout, 61 GB of B in HBM.
-usage: python tools/run_w50.py [n_waters] [eigh|sp2] [xs]"""
+usage: python tools/run_w50.py [n_waters] [eigh|sp2] [xs|dense]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +21,8 @@ if len(sys.argv) > 2:
     flags["density_solver"] = sys.argv[2]                       # eigh | sp2
 if len(sys.argv) > 3 and sys.argv[3] == "xs":
     flags["df_exchange_screen"] = True                          # the reference's block-screened exchange (ScreenedDF.jl:431-447)
+if len(sys.argv) > 3 and sys.argv[3] == "dense":
+    flags["df_force_dense"] = True                              # the unscreened (Q, N^2) map (DensityFitting.jl:78-90; 60 GB of B at N = 1250)
 res = rhf.run(atoms, b["charges"], b["basis"], b["aux_basis"], flags, output=2)
 wall = time.perf_counter() - t0
 tm = res["Timings"]
@@ -34,3 +36,7 @@ print("HOMO %.6f  LUMO %.6f  gap %.6f Eh" % (eps[o - 1], eps[o], eps[o] - eps[o 
 print("density solver %s; exchange screening blocks %s" % (res["Density Solver"], tm.non_timing_data.get("df_exchange_screen_blocks")))
 print("last Fock build: " + ", ".join("%s %.2f ms" % (k["name"], 1e3 * k["seconds"]) for k in res["Kernel Stats"]) +
       "; device memory %.1f GB" % (res["Device Bytes"] / 1e9))
+it = res["Iteration Times"]
+print("iteration wall times (ms): " + " ".join("%.1f" % (1e3 * t) for t in it))
+tail = sorted(it[len(it) // 2:])
+print("median of the second half: %.2f ms per iteration" % (1e3 * tail[len(tail) // 2]))
