@@ -314,7 +314,8 @@ def measure_w50(args, world, rank, local, dev, barrier, kept, density_solver=Non
         if si[6] != 1.0:
             out["sp2_last_projection"]["note"] = ("not accelerated: the distance to the last diagonalised matrix exceeds half its HOMO-LUMO gap "
                                                   "(a synthetic SCF that has not settled — see last_density_change — keeps it there; "
-                                                  "profiles/r04_sp2_w50_trend.txt)")
+                                                  "profiles/r04_sp2_w50_trend.txt; the real (H2O)50 with this map: 1.7 ms of replicated work "
+                                                  "per accelerated iteration, profiles/r04_w50_real_dense_sp2.txt)")
     if args.in_process:
         out["group"] = dict(gtm, transport=fb.g.transport())
     fb.close()
